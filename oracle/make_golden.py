@@ -1,0 +1,287 @@
+"""Generate the golden vectors in tests/golden/ from the REFERENCE's own Python.
+
+TEST INFRASTRUCTURE ONLY -- runs in the build container (where /root/reference
+is mounted), never on the GPU box and never from the product path.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.pt
+
+The reference modules are imported from /root/reference unmodified; every
+fixture stores inputs, the module's state_dict, outputs and (where stated)
+gradients produced by the reference on CPU in fp32, eval() mode.  The fixtures
+are data only (tensors + plain-python configs): no reference source is copied.
+"""
+import os
+import sys
+
+import torch
+
+REF = os.environ.get("HDMOE_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "Utils"))
+
+import models.model_internals as mi          # noqa: E402  (reference)
+import models.model_components as mc         # noqa: E402  (reference)
+import models.model_config1 as c1            # noqa: E402  (reference)
+import models.model_config2 as c2            # noqa: E402  (reference)
+import utils as ru                           # noqa: E402  (reference Utils/utils.py)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+TINY = dict(IN_in_channels=4, IN_img_resolution=16, internal_channels=8, time_emb_dim=16, text_emb_dim=32,
+            num_experts=4, top_k=2, Fourier_bandwidth=1.0, VIT_num_blocks=1, VIT_patch_sizes=[2, 4, 4, 8],
+            VIT_num_groups=2, VIT_num_heads=2, VIT_emb_size=8, Unet_num_blocks=1, Unet_channel_mult=[1, 2],
+            Unet_kernel_sizes=[(3, 3), (3, 3), (5, 5), (5, 5)], Unet_model_channels=8,
+            Unet_channel_mult_emb=2, sigma_data=0.5, log_var_channels=8)
+LOSS = dict(unet_bal=0.05, vit_bal=0.1, z_bal=0.005)
+
+
+def sd(mod):
+    return {k: v.detach().clone() for k, v in mod.state_dict().items()}
+
+
+def wake_zero_inits(mod, gen):
+    """Zero-initialised learnables would make expert outputs identically 0 and
+    the fixture vacuous: give them seeded non-trivial values."""
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if name.endswith("out_gain"):
+                p.fill_(0.7)
+            elif name.endswith("alpha_txt"):
+                p.fill_(0.3)
+            elif name.endswith("rel_pos_bias") or name.endswith("pos_emb"):
+                p.copy_(0.3 * torch.randn(p.shape, generator=gen))
+            elif name.endswith(".weight") and p.ndim == 1:          # GroupNorm / LayerNorm affine
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif name.endswith(".bias") and p.ndim == 1:
+                p.copy_(0.2 * torch.randn(p.shape, generator=gen))
+
+
+def grads_of(mod, names):
+    named = dict(mod.named_parameters())
+    return {n: (named[n].grad.detach().clone() if named[n].grad is not None else None) for n in names}
+
+
+def full_model(variant):
+    torch.manual_seed(1)
+    gen = torch.Generator().manual_seed(7)
+    cls = c1.preconditioned_HDMOEM if variant == 1 else c2.preconditioned_HDMOEM
+    model = cls(**TINY).eval()
+    wake_zero_inits(model, gen)
+    B, E = 6, TINY["num_experts"]
+    x0 = 0.5 * torch.randn(B, 4, 16, 16, generator=gen)
+    sigma = torch.tensor([0.05, 0.3, 0.9, 2.5, 11.0, 60.0]).view(B, 1, 1, 1)
+    x = (x0 + sigma * torch.randn(B, 4, 16, 16, generator=gen)).requires_grad_(True)
+    text = torch.randn(B, 5, TINY["text_emb_dim"], generator=gen)
+    um = torch.tensor([[1, 1, 0, 0], [1, 1, 1, 0], [0, 1, 1, 1], [1, 1, 1, 1], [0, 0, 1, 1], [1, 0, 1, 1.]])
+    vm = torch.tensor([[1, 1, 1, 1], [1, 0, 1, 1], [1, 1, 0, 1], [0, 1, 1, 0], [1, 1, 1, 0], [0, 1, 1, 1.]])
+    kw = dict(x=x, sigma=sigma, text_emb=text, Unet_router_mask=um, Vit_router_mask=vm, zeta=0.0,
+              return_log_var=True)
+    extra = {}
+    if variant == 2:
+        extra = dict(transition_point=-1.2, softness=1.6)
+    out = model(**kw, **extra)
+    crit = ru.EDM_LOSS(num_experts=E, sigma_data=0.5, Unet_bal=LOSS["unet_bal"], vit_bal=LOSS["vit_bal"],
+                       z_bal=LOSS["z_bal"], prior_bal=0.0)
+    loss = crit(sigma_vec=sigma, x=x0, sigma=sigma, out_model=out)
+    loss["loss"].backward()
+    k = TINY["top_k"]
+    idx, margin = {}, {}
+    for key in ("Unet_raw", "vit_raw"):
+        vals, ind = torch.topk(out[key].detach(), k + 1, dim=-1)
+        idx[key] = ind[:, :k].clone()
+        margin[key] = (vals[:, k - 1] - vals[:, k]).clone()
+    pnames = ["net.input_proj.weights", "net.out_fourier1.weights", "net.Unet_router.hard_route.0.weights",
+              "net.Unet_router.hard_route.4.weight", "net.vit_router.linear.weights",
+              "net.Unet_experts.0.encoders.16x16_conv.weights", "net.Unet_experts.2.decoders.8x8_in0.conv_res1.weights",
+              "net.Unet_experts.1.out_gain", "net.VIT_experts.0.diffit.0.TMSA.rel_pos_bias",
+              "net.VIT_experts.1.patch.weight", "net.VIT_experts.3.unpatch_proj.weights",
+              "net.cross_attn.q_proj.weights", "net.cross_attn_text.k_proj.weights", "net.alpha_txt",
+              "net.gate2.weights", "net.output_proj.weights", "log_var_linear.weights"]
+    if variant == 1:
+        pnames.append("net.scaling_net.soft_route.0.weights")
+    fx = dict(variant=variant, cfg=TINY, loss_cfg=LOSS, state=sd(model), x0=x0, sigma=sigma, x=x.detach().clone(),
+              text=text, unet_mask=um, vit_mask=vm, extra=extra,
+              out={k_: (v.detach().clone() if v is not None else None) for k_, v in out.items()},
+              loss={k_: (v.detach().clone() if torch.is_tensor(v) else v) for k_, v in loss.items()},
+              topk_idx=idx, topk_margin=margin, x_grad=x.grad.detach().clone(), param_grads=grads_of(model, pnames))
+    torch.save(fx, os.path.join(OUT, f"full_config{variant}.pt"))
+    print(f"full_config{variant}: denoised {tuple(out['denoised'].shape)} loss {float(loss['loss']):.6f} "
+          f"min margin U {float(margin['Unet_raw'].min()):.4f} V {float(margin['vit_raw'].min()):.4f}")
+
+
+def components():
+    gen = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    cases = {}
+
+    # ---- L0 free functions -------------------------------------------------
+    x = rn(3, 6, 5, 5)
+    cases["normalize_default"] = dict(x=x, out=mi.normalize(x))
+    cases["normalize_dim1"] = dict(x=x, out=mi.normalize(x, dim=[1]))
+    cases["mp_silu"] = dict(x=x, out=mi.mp_silu(x))
+    a, b = rn(2, 4, 3, 3), rn(2, 4, 3, 3)
+    cases["mp_sum_t03"] = dict(a=a, b=b, t=0.3, out=mi.mp_sum(a, b, 0.3))
+    b2 = rn(2, 7, 3, 3)
+    cases["mp_cat_t05"] = dict(a=a, b=b2, t=0.5, out=mi.mp_cat(a, b2, dim=1, t=0.5))
+    cases["mp_cat_t07"] = dict(a=a, b=b2, t=0.7, out=mi.mp_cat(a, b2, dim=1, t=0.7))
+    y = rn(2, 3, 8, 6)
+    cases["resample_down"] = dict(x=y, out=mi.resample(y, mode="down"))
+    cases["resample_up"] = dict(x=y, out=mi.resample(y, mode="up"))
+    torch.manual_seed(3)
+    fo = mi.MP_Fourier(10, bandwidth=1.5)
+    t = rn(5)
+    cases["mp_fourier"] = dict(state=sd(fo), x=t, out=fo(t))
+
+    # ---- MP_Conv -------------------------------------------------------------
+    for name, cin, cout, kern, shape in [("lin", 12, 7, (), (5, 12)), ("1x1", 6, 9, (1, 1), (2, 6, 5, 4)),
+                                         ("3x3", 5, 8, (3, 3), (2, 5, 7, 6)), ("5x5", 4, 6, (5, 5), (2, 4, 9, 8)),
+                                         ("4x4even", 3, 5, (4, 4), (2, 3, 6, 7)), ("7x7", 3, 4, (7, 7), (1, 3, 8, 8))]:
+        torch.manual_seed(5)
+        conv = mi.MP_Conv(cin, cout, kern).eval()
+        xx = rn(*shape).requires_grad_(True)
+        out = conv(xx, gain=1.3)
+        go = rn(*out.shape)
+        out.backward(go)
+        cases[f"mp_conv_{name}"] = dict(state=sd(conv), x=xx.detach().clone(), gain=1.3, out=out.detach().clone(),
+                                        grad_out=go, x_grad=xx.grad.clone(), w_grad=conv.weights.grad.clone())
+
+    # ---- MP_Attention ----------------------------------------------------------
+    def attn_case(name, heads, emb, s0, time_dim, ctx_dim, cross, sq, skv, balance=0.5, gain_t=0.8):
+        torch.manual_seed(9)
+        at = mi.MP_Attention(heads, emb, s0, time_dim=time_dim, context_dim=ctx_dim, attn_balance=balance,
+                             is_cross_attn=cross).eval()
+        wake_zero_inits(at, gen)
+        q = rn(3, sq, emb).requires_grad_(True)
+        ctx = rn(3, skv, ctx_dim if ctx_dim else emb).requires_grad_(True) if cross else None
+        te = rn(3, 1, time_dim).requires_grad_(True) if time_dim else None
+        out = at(q, 1.1, gain_t, context=ctx, time_embedding=te)
+        go = rn(*out.shape)
+        out.backward(go)
+        names = [n for n, _ in at.named_parameters()]
+        cases[f"attn_{name}"] = dict(
+            state=sd(at), heads=heads, cross=cross, balance=balance, gain_s=1.1, gain_t=gain_t,
+            q=q.detach().clone(), ctx=None if ctx is None else ctx.detach().clone(),
+            te=None if te is None else te.detach().clone(), out=out.detach().clone(), grad_out=go,
+            q_grad=q.grad.clone(), ctx_grad=None if ctx is None else ctx.grad.clone(),
+            te_grad=None if te is None else te.grad.clone(), param_grads=grads_of(at, names))
+
+    attn_case("self_time", 2, 8, 9, 6, None, False, 9, 9)
+    attn_case("self_slice", 2, 8, 9, 6, None, False, 6, 6)
+    attn_case("self_bicubic", 2, 8, 6, 0, None, False, 10, 10)
+    attn_case("cross", 4, 16, 12, 0, 16, True, 12, 12)
+    attn_case("cross_text", 4, 16, 12, 0, 24, True, 12, 5, balance=0.3)
+    attn_case("cross_time_q", 2, 8, 7, 6, 8, True, 7, 11)
+
+    # ---- routers ----------------------------------------------------------------
+    for name, k, mask in [("k1", 1, None), ("k2", 2, None),
+                          ("k2_masked", 2, torch.tensor([[1, 1, 0, 1, 1], [0, 1, 1, 0, 1], [1, 1, 1, 1, 1], [1, 0, 0, 1, 0.]])),
+                          ("k1_allmasked_row", 1, torch.tensor([[1, 1, 1, 1, 1], [0, 0, 0, 0, 0], [1, 0, 1, 0, 1], [0, 0, 0, 1, 1.]]))]:
+        torch.manual_seed(13)
+        r = mc.Router(in_channels=4, time_dim=6, top_k=k, num_experts=5).eval()
+        wake_zero_inits(r, gen)
+        xx = rn(4, 4, 8, 8).requires_grad_(True)
+        te = rn(4, 6)
+        sw, gp, lg = r(x=xx, time_emb=te, zeta=0.0, mask=mask)
+        fin = torch.isfinite(gp)
+        ((torch.where(fin, gp, torch.zeros_like(gp)) ** 2).sum() + (sw[torch.isfinite(sw)] * 0.37).sum()).backward()
+        cases[f"router_{name}"] = dict(state=sd(r), k=k, x=xx.detach().clone(), te=te, mask=mask, sparse=sw.detach().clone(),
+                                       probs=gp.detach().clone(), logits=lg.detach().clone(), x_grad=xx.grad.clone(),
+                                       idx=torch.topk(lg.detach(), k, dim=-1).indices)
+    torch.manual_seed(17)
+    s = mc.Scaling_router(emb_dim=6, num_experts=2).eval()
+    wake_zero_inits(s, gen)
+    te = rn(5, 6)
+    cases["scaling_router"] = dict(state=sd(s), x=te, out=s(te, zeta=0.0).detach().clone())
+
+    # ---- UNet blocks / expert -------------------------------------------------------
+    def block_case(name, cin, cout, kern, res, typ, hw):
+        torch.manual_seed(19)
+        blk = mc.Unet_block(cin, cout, kern, emb_size=10, resample=res, Type=typ).eval()
+        xx = rn(2, cin, *hw).requires_grad_(True)
+        e = rn(2, 10).requires_grad_(True)
+        out = blk(xx, e)
+        go = rn(*out.shape)
+        out.backward(go)
+        cases[f"unet_block_{name}"] = dict(state=sd(blk), kind=typ, mode=res, x=xx.detach().clone(), emb=e.detach().clone(),
+                                           out=out.detach().clone(), grad_out=go, x_grad=xx.grad.clone(),
+                                           emb_grad=e.grad.clone(),
+                                           param_grads=grads_of(blk, [n for n, _ in blk.named_parameters()]))
+
+    block_case("enc_keep", 6, 6, (3, 3), "keep", "enc", (8, 8))
+    block_case("enc_skip", 4, 8, (3, 3), "keep", "enc", (8, 8))
+    block_case("enc_down", 6, 6, (5, 5), "down", "enc", (8, 8))
+    block_case("dec_skip", 10, 6, (3, 3), "keep", "dec", (6, 6))
+    block_case("dec_up", 6, 6, (3, 3), "up", "dec", (4, 4))
+
+    torch.manual_seed(23)
+    ue = mc.Unet_expert(img_resolution=8, img_channels=4, time_emb_dim=6, text_emb_dim=5, channel_mult=[1, 2],
+                        model_channels=8, channel_mult_emb=2, num_blocks=1, kernel_size=(3, 3)).eval()
+    wake_zero_inits(ue, gen)
+    xx, te, tx = rn(2, 4, 8, 8).requires_grad_(True), rn(2, 6), rn(2, 3, 5)
+    out = ue(xx, te, tx)
+    go = rn(*out.shape)
+    out.backward(go)
+    cases["unet_expert"] = dict(state=sd(ue), x=xx.detach().clone(), te=te, text=tx, out=out.detach().clone(),
+                                grad_out=go, x_grad=xx.grad.clone(),
+                                param_grads=grads_of(ue, ["out_gain", "map_text.weights", "encoders.8x8_conv.weights",
+                                                          "decoders.4x4_block0.conv_skip.weights"]))
+    out_nt = ue(xx.detach(), te, None)
+    cases["unet_expert_notext"] = dict(state=sd(ue), x=xx.detach().clone(), te=te, text=None, out=out_nt.detach().clone())
+
+    # ---- ViT block / expert -----------------------------------------------------------
+    for name, cch, emb in [("same", 8, 8), ("skip_proj", 6, 8)]:
+        torch.manual_seed(29)
+        vb = mc.Vit_block(num_heads=2, num_groups=2, num_channels=cch, seq_ln=9, emb_dim=emb, time_dim=6).eval()
+        wake_zero_inits(vb, gen)
+        xx, te = rn(3, 9, cch).requires_grad_(True), rn(3, 6).requires_grad_(True)
+        out = vb(xx, te)
+        go = rn(*out.shape)
+        out.backward(go)
+        cases[f"vit_block_{name}"] = dict(state=sd(vb), heads=2, groups=2, x=xx.detach().clone(), te=te.detach().clone(),
+                                          out=out.detach().clone(), grad_out=go, x_grad=xx.grad.clone(),
+                                          te_grad=te.grad.clone(),
+                                          param_grads=grads_of(vb, [n for n, _ in vb.named_parameters()]))
+    for name, res, p in [("div", 8, 4), ("ragged", 10, 4)]:
+        torch.manual_seed(31)
+        hp = -(-res // p)
+        ve = mc.Vit_expert(num_heads=2, num_groups=2, in_channels=4, seq_ln=hp * hp, emb_dim=8, num_blocks=2,
+                           patch_size=p, time_dim=6, text_dim=5).eval()
+        wake_zero_inits(ve, gen)
+        xx, te, tx = rn(2, 4, res, res).requires_grad_(True), rn(2, 6), rn(2, 5)
+        out = ve(xx, te, tx)
+        go = rn(*out.shape)
+        out.backward(go)
+        cases[f"vit_expert_{name}"] = dict(state=sd(ve), heads=2, groups=2, x=xx.detach().clone(), te=te, text=tx,
+                                           out=out.detach().clone(), grad_out=go, x_grad=xx.grad.clone(),
+                                           param_grads=grads_of(ve, ["patch.weight", "patch.bias", "pos_emb",
+                                                                     "unpatch_proj.weights", "norm.weight"]))
+
+    # ---- dispatch with an expert that receives no sample ---------------------------------
+    torch.manual_seed(37)
+    bank = torch.nn.ModuleList([mc.Unet_expert(img_resolution=8, img_channels=4, time_emb_dim=6, text_emb_dim=5,
+                                               channel_mult=[1], model_channels=8, channel_mult_emb=1, num_blocks=1,
+                                               kernel_size=ks) for ks in [(3, 3), (5, 5), (3, 3)]]).eval()
+    wake_zero_inits(bank, gen)
+    xx, te, tx = rn(5, 4, 8, 8), rn(5, 6), rn(5, 2, 5)
+    w = torch.tensor([[0.6, 0.0, 0.4], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.3, 0.0, 0.7], [0.0, 0.0, 0.0]])
+    out = c2.router_to_unet_experts(xx, bank, w, te, tx)
+    cases["dispatch_empty_expert"] = dict(state=sd(bank), x=xx, te=te, text=tx, w=w, out=out.detach().clone())
+
+    # ---- loss / input generators (rows N2) ------------------------------------------------
+    sig = torch.tensor([0.01, 0.2, 0.5, 1.0, 3.0, 20.0, 79.0])
+    mg = ru.MaskGenerator(expert_attributes=[3, 3, 5, 5], p_mean=-1.2, p_std=1.6, bandwidth=0.3, max_bandwidth=0.8,
+                          min_active=1, total_steps=5000, step_size=0.1, noise_range=(0.0, 0.6), strat_band="step")
+    cases["mask_generator"] = dict(sigma=sig, attrs=[3, 3, 5, 5], p_mean=-1.2, p_std=1.6, bandwidth=0.3,
+                                   noise_range=(0.0, 0.6), out=mg(sig, 0))
+    torch.save(cases, os.path.join(OUT, "components.pt"))
+    print(f"components: {len(cases)} cases")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    components()
+    full_model(1)
+    full_model(2)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

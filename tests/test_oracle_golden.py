@@ -1,0 +1,164 @@
+"""Pin the CPU oracle (oracle/hdmoe_oracle.py) against golden vectors produced
+by the reference's own Python (oracle/make_golden.py).  CPU only."""
+import torch
+
+from oracle import hdmoe_oracle as O
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def close(a, b, **kw):
+    kw = {**TOL, **kw}
+    torch.testing.assert_close(a, b, equal_nan=True, **kw)
+
+
+def test_free_functions(golden_components):
+    g = golden_components
+    close(O.normalize(g["normalize_default"]["x"]), g["normalize_default"]["out"])
+    close(O.normalize(g["normalize_dim1"]["x"], dim=[1]), g["normalize_dim1"]["out"])
+    close(O.mp_silu(g["mp_silu"]["x"]), g["mp_silu"]["out"])
+    c = g["mp_sum_t03"]
+    close(O.mp_sum(c["a"], c["b"], c["t"]), c["out"])
+    for name in ("mp_cat_t05", "mp_cat_t07"):
+        c = g[name]
+        close(O.mp_cat(c["a"], c["b"], 1, c["t"]), c["out"])
+    close(O.resample(g["resample_down"]["x"], "down"), g["resample_down"]["out"])
+    close(O.resample(g["resample_up"]["x"], "up"), g["resample_up"]["out"])
+    c = g["mp_fourier"]
+    close(O.mp_fourier(c["x"], c["state"]["freqs"], c["state"]["phases"]), c["out"])
+
+
+def test_mp_conv(golden_components):
+    for name in ("lin", "1x1", "3x3", "5x5", "4x4even", "7x7"):
+        c = golden_components[f"mp_conv_{name}"]
+        x = c["x"].clone().requires_grad_(True)
+        w = c["state"]["weights"].clone().requires_grad_(True)
+        out = O.mp_conv(x, w, c["gain"])
+        close(out, c["out"])
+        out.backward(c["grad_out"])
+        close(x.grad, c["x_grad"])
+        close(w.grad, c["w_grad"], atol=1e-5)
+
+
+def test_attention(golden_components):
+    for name in ("self_time", "self_slice", "self_bicubic", "cross", "cross_text", "cross_time_q"):
+        c = golden_components[f"attn_{name}"]
+        P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+        q = c["q"].clone().requires_grad_(True)
+        ctx = None if c["ctx"] is None else c["ctx"].clone().requires_grad_(True)
+        te = None if c["te"] is None else c["te"].clone().requires_grad_(True)
+        out = O.mp_attention(P, "", q, c["gain_s"], c["gain_t"], c["heads"], context=ctx, time_embedding=te,
+                             attn_balance=c["balance"])
+        close(out, c["out"])
+        out.backward(c["grad_out"])
+        close(q.grad, c["q_grad"], atol=1e-5)
+        if ctx is not None:
+            close(ctx.grad, c["ctx_grad"], atol=1e-5)
+        if te is not None:
+            close(te.grad, c["te_grad"], atol=1e-5)
+        for n, gref in c["param_grads"].items():
+            if gref is not None:
+                close(P[n].grad, gref, atol=1e-5)
+
+
+def test_routers(golden_components):
+    for name in ("k1", "k2", "k2_masked", "k1_allmasked_row"):
+        c = golden_components[f"router_{name}"]
+        x = c["x"].clone().requires_grad_(True)
+        sw, gp, lg = O.router(c["state"], "", x, c["te"], c["mask"], c["k"])
+        close(lg, c["logits"])
+        close(gp, c["probs"])
+        rows_ok = torch.isfinite(c["sparse"]).all(dim=1)
+        close(sw[rows_ok], c["sparse"][rows_ok])
+        assert torch.equal(torch.topk(lg[rows_ok], c["k"], dim=-1).indices, c["idx"][rows_ok])
+        fin = torch.isfinite(gp)
+        ((torch.where(fin, gp, torch.zeros_like(gp)) ** 2).sum() + (sw[torch.isfinite(sw)] * 0.37).sum()).backward()
+        close(x.grad, c["x_grad"], atol=1e-5)
+    c = golden_components["scaling_router"]
+    close(O.scaling_router(c["state"], "", c["x"]), c["out"])
+
+
+def test_unet(golden_components):
+    for name in ("enc_keep", "enc_skip", "enc_down", "dec_skip", "dec_up"):
+        c = golden_components[f"unet_block_{name}"]
+        P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        e = c["emb"].clone().requires_grad_(True)
+        out = O.unet_block(P, "", x, e, c["kind"], c["mode"])
+        close(out, c["out"])
+        out.backward(c["grad_out"])
+        close(x.grad, c["x_grad"], atol=1e-5)
+        close(e.grad, c["emb_grad"], atol=1e-5)
+        for n, gref in c["param_grads"].items():
+            close(P[n].grad, gref, atol=1e-5)
+    c = golden_components["unet_expert"]
+    P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+    x = c["x"].clone().requires_grad_(True)
+    out = O.unet_expert(P, "", x, c["te"], c["text"])
+    close(out, c["out"])
+    out.backward(c["grad_out"])
+    close(x.grad, c["x_grad"], rtol=1e-4, atol=1e-4)     # ~40-layer fp32 chain: summation-order noise
+    for n, gref in c["param_grads"].items():
+        close(P[n].grad, gref, rtol=1e-4, atol=1e-4)
+    c = golden_components["unet_expert_notext"]
+    close(O.unet_expert(c["state"], "", c["x"], c["te"], None), c["out"])
+
+
+def test_vit(golden_components):
+    for name in ("same", "skip_proj"):
+        c = golden_components[f"vit_block_{name}"]
+        P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        te = c["te"].clone().requires_grad_(True)
+        out = O.vit_block(P, "", x, te, c["heads"], c["groups"])
+        close(out, c["out"])
+        out.backward(c["grad_out"])
+        close(x.grad, c["x_grad"], atol=1e-5)
+        close(te.grad, c["te_grad"], atol=1e-5)
+        for n, gref in c["param_grads"].items():
+            close(P[n].grad, gref, atol=1e-5)
+    for name in ("div", "ragged"):
+        c = golden_components[f"vit_expert_{name}"]
+        P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        out = O.vit_expert(P, "", x, c["te"], c["text"], c["heads"], c["groups"])
+        close(out, c["out"])
+        out.backward(c["grad_out"])
+        close(x.grad, c["x_grad"], rtol=1e-4, atol=1e-4)
+        for n, gref in c["param_grads"].items():
+            close(P[n].grad, gref, rtol=1e-4, atol=1e-4)
+
+
+def test_dispatch_and_masks(golden_components):
+    c = golden_components["dispatch_empty_expert"]
+    out = O.dispatch_experts(c["x"], c["w"], c["te"], c["text"],
+                             lambda e, xs, ts, tx: O.unet_expert(c["state"], f"{e}.", xs, ts, tx))
+    close(out, c["out"])
+    assert float(out[4].abs().max()) == 0.0            # the un-routed sample gets exactly zero
+    c = golden_components["mask_generator"]
+    m = O.mask_generator(c["sigma"], c["attrs"], c["p_mean"], c["p_std"], c["bandwidth"], 1, c["noise_range"])
+    assert torch.equal(m, c["out"])
+
+
+def test_full_model(golden_full):
+    g = golden_full
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g["state"].items()}
+    x = g["x"].clone().requires_grad_(True)
+    out = O.preconditioned_hdmoem(P, g["cfg"], g["variant"], x, g["sigma"], g["text"], g["unet_mask"],
+                                  g["vit_mask"], return_log_var=True, **g["extra"])
+    for key, ref in g["out"].items():
+        close(out[key], ref, rtol=1e-4, atol=1e-5)
+    k = g["cfg"]["top_k"]
+    for key in ("Unet_raw", "vit_raw"):                # router indices: bit-exact
+        assert torch.equal(torch.topk(out[key], k, dim=-1).indices, g["topk_idx"][key])
+    lc = g["loss_cfg"]
+    loss = O.edm_loss(out, g["x0"], g["cfg"]["num_experts"], lc["unet_bal"], lc["vit_bal"], lc["z_bal"])
+    for key in ("loss", "denoising", "balance", "z_loss", "pure_loss"):
+        close(loss[key], g["loss"][key], rtol=1e-5, atol=1e-6)
+    loss["loss"].backward()
+    close(x.grad, g["x_grad"], rtol=1e-3, atol=1e-6)
+    for n, gref in g["param_grads"].items():
+        if gref is None:
+            assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0
+        else:
+            close(P[n].grad, gref, rtol=1e-3, atol=1e-6)
