@@ -95,7 +95,7 @@ def test_unet(golden_components):
     P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
     x = c["x"].clone().requires_grad_(True)
     out = O.unet_expert(P, "", x, c["te"], c["text"])
-    close(out, c["out"])
+    close(out, c["out"], rtol=1e-4, atol=1e-4)
     out.backward(c["grad_out"])
     close(x.grad, c["x_grad"], rtol=1e-4, atol=1e-4)     # ~40-layer fp32 chain: summation-order noise
     for n, gref in c["param_grads"].items():
