@@ -12,6 +12,13 @@ def close(a, b, **kw):
     torch.testing.assert_close(a, b, equal_nan=True, **kw)
 
 
+def close_scaled(a, b, rel=2e-5):
+    """max|a-b| <= rel * max|b|: for gradients through deep fp32 chains, whose
+    element-wise error is set by the largest terms of the sums, not by each element."""
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= rel * max(scale, 1e-6), (float((a - b).abs().max()), scale)
+
+
 def test_free_functions(golden_components):
     g = golden_components
     close(O.normalize(g["normalize_default"]["x"]), g["normalize_default"]["out"])
@@ -97,9 +104,9 @@ def test_unet(golden_components):
     out = O.unet_expert(P, "", x, c["te"], c["text"])
     close(out, c["out"], rtol=1e-4, atol=1e-4)
     out.backward(c["grad_out"])
-    close(x.grad, c["x_grad"], rtol=1e-4, atol=1e-4)     # ~40-layer fp32 chain: summation-order noise
+    close_scaled(x.grad, c["x_grad"])                    # ~40-layer fp32 chain: summation-order noise
     for n, gref in c["param_grads"].items():
-        close(P[n].grad, gref, rtol=1e-4, atol=1e-4)
+        close_scaled(P[n].grad, gref)
     c = golden_components["unet_expert_notext"]
     close(O.unet_expert(c["state"], "", c["x"], c["te"], None), c["out"])
 
@@ -124,9 +131,9 @@ def test_vit(golden_components):
         out = O.vit_expert(P, "", x, c["te"], c["text"], c["heads"], c["groups"])
         close(out, c["out"])
         out.backward(c["grad_out"])
-        close(x.grad, c["x_grad"], rtol=1e-4, atol=1e-4)
+        close_scaled(x.grad, c["x_grad"])
         for n, gref in c["param_grads"].items():
-            close(P[n].grad, gref, rtol=1e-4, atol=1e-4)
+            close_scaled(P[n].grad, gref)
 
 
 def test_dispatch_and_masks(golden_components):
