@@ -108,7 +108,7 @@ def test_unet(golden_components):
     for n, gref in c["param_grads"].items():
         close_scaled(P[n].grad, gref)
     c = golden_components["unet_expert_notext"]
-    close(O.unet_expert(c["state"], "", c["x"], c["te"], None), c["out"])
+    close(O.unet_expert(c["state"], "", c["x"], c["te"], None), c["out"], rtol=1e-4, atol=1e-4)
 
 
 def test_vit(golden_components):
