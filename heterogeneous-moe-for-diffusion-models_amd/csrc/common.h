@@ -1,0 +1,108 @@
+// Shared device/host helpers for the HDMOE HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HDMOE_OK 0
+#define HDMOE_EINVAL (-1)
+#define HDMOE_EDTYPE (-2)
+#define HDMOE_ELAUNCH (-3)
+
+// dtype codes of the C ABI
+#define HDMOE_F32 0
+#define HDMOE_BF16 1
+
+#define HDMOE_MAX_GROUPS 8
+#define MP_SILU_DIV 0.596f
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DEVI __device__ __forceinline__
+
+DEVI float to_f(float v) { return v; }
+DEVI float to_f(bf16 v) { return (float)v; }
+template <typename T> DEVI T from_f(float v);
+template <> DEVI float from_f<float>(float v) { return v; }
+template <> DEVI bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// ---- 8-element fragments (one MFMA operand slice per lane) -----------------
+template <typename T> struct Frag8;
+template <> struct Frag8<bf16> {
+  bf16x8 v;
+  DEVI void zero() { v = (bf16x8)(0); }
+  DEVI void set(int j, float f) { v[j] = (bf16)f; }
+  DEVI float get(int j) const { return (float)v[j]; }
+};
+template <> struct Frag8<float> {
+  float v[8];
+  DEVI void zero() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  DEVI void set(int j, float f) { v[j] = f; }
+  DEVI float get(int j) const { return v[j]; }
+};
+
+// aligned 8-element load (16 B for bf16, 2x16 B for f32); p must be 16-B aligned
+DEVI void load8(Frag8<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const bf16x8*>(p); }
+DEVI void load8(Frag8<float>& f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+// D(32x32) += A(32x16) * B(16x32).  Lane l = (r = l & 31, h = l >> 5) holds
+// A[r][8h + j] and B[8h + j][r] in element j.  For f32 the 16-deep step is
+// eight 32x32x2 MFMAs; MFMA j contracts the k-slots {8*0 + j, 8*1 + j}, the
+// same slot->k map on both operands, so the sum over k is unchanged.
+DEVI void mma32(f32x16& acc, const Frag8<bf16>& a, const Frag8<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+DEVI void mma32(f32x16& acc, const Frag8<float>& a, const Frag8<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+// accumulator element `reg` of lane l sits at row (reg&3) + 8*(reg>>2) + 4*(l>>5), col l&31
+DEVI int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ---- reductions -----------------------------------------------------------------
+DEVI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `sm` >= 16 floats; all threads get the result
+DEVI float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sm[i];
+  return t;
+}
+
+DEVI float silu_f(float x) { return x / (1.f + __expf(-x)); }
+DEVI float mp_silu_f(float x) { return silu_f(x) * (1.f / MP_SILU_DIV); }
+// d/dx [silu(x)/0.596]
+DEVI float mp_silu_grad_f(float x) {
+  const float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s)) * (1.f / MP_SILU_DIV);
+}
+
+static inline int hdmoe_launch_status() {
+  return hipGetLastError() == hipSuccess ? HDMOE_OK : HDMOE_ELAUNCH;
+}
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }

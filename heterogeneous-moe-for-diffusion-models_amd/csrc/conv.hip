@@ -1,0 +1,442 @@
+// K3: magnitude-preserving weight prep + grouped implicit-GEMM convolution (fwd / dgrad) + wgrad.
+//
+// Replaces MP_Conv.forward (reference models/model_internals.py:253-275: normalize -> gain/sqrt(fan_in)
+// -> cast -> F.conv2d / F.linear) and its autograd.  Activations are NHWC ([N][H][W][C], C contiguous);
+// "grouped" = the sample rows of one launch belong to up to 8 experts with their own weights and their
+// own kernel size (heterogeneous 3x3 / 5x5 / 7x7 experts in one launch); seg[g]..seg[g+1] is the row
+// range of group g (device memory, produced by the dispatch plan, so no host sync is needed).
+//
+// GEMM view (fwd and dgrad):  M = output pixels, N = output channels, K = taps * input channels.
+//   * each wave owns a 32-pixel x (32*NB)-channel tile; MFMA 32x32x16 (bf16) or 8x 32x32x2 (f32)
+//   * K is walked tap-major in 16-channel chunks; operands come from global memory as 16-B vectors
+// wgrad:  M = out channels, N = in channels, K = pixels, one tap per wave, fp32 atomics into a
+//   [tap][O][I] slab (contiguous I => full-rate atomic shape, MI355X_MICROARCH "Global float atomics").
+#include "common.h"
+#include "hdmoe.h"
+
+namespace {
+
+// ------------------------------------------------------------------ weight prep
+struct WprepArgs {
+  float* w_raw[HDMOE_MAX_GROUPS];        // (O, I, kh, kw) fp32 (written when mutate)
+  const float* gain_ptr[HDMOE_MAX_GROUPS];
+  void* wf;                              // [g][tap][O][Ipad]
+  void* wd;                              // [g][tap'][I][Opad]   (may be null)
+  long wf_stride, wd_stride;             // elements per group
+  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS];
+  int O, I, Ipad, Opad;
+  float gain_val;
+  int normalize, mutate, flip;
+};
+
+template <typename T>
+__global__ __launch_bounds__(128) void wprep_fwd_kernel(WprepArgs a) {
+  __shared__ float sm[16];
+  const int o = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int taps = a.kh[g] * a.kw[g];
+  const int fan = a.I * taps;
+  T* wf = (T*)a.wf + (long)g * a.wf_stride;
+  T* wd = a.wd ? (T*)a.wd + (long)g * a.wd_stride : nullptr;
+  if (o >= a.O) {                                   // pad rows of the dgrad layout
+    if (wd && o < a.Opad)
+      for (int e = tid; e < fan; e += blockDim.x) {
+        const int i = e / taps, t = e % taps;
+        const int td = a.flip ? taps - 1 - t : t;
+        wd[((long)td * a.I + i) * a.Opad + o] = from_f<T>(0.f);
+      }
+    return;
+  }
+  float* w = a.w_raw[g] + (long)o * fan;
+  float scale = 1.f;
+  if (a.normalize) {
+    const float c = rsqrtf((float)fan);
+    float ss = 0.f;
+    for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; ss += v * v; }
+    ss = block_sum(ss, sm);
+    float inv = 1.f / (1e-4f + sqrtf(ss) * c);
+    if (a.mutate) {                                 // reference: weights.copy_(normalize(w)) then normalize again
+      for (int e = tid; e < fan; e += blockDim.x) w[e] = w[e] * inv;
+      __syncthreads();
+      float s2 = 0.f;
+      for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; s2 += v * v; }
+      s2 = block_sum(s2, sm);
+      inv = 1.f / (1e-4f + sqrtf(s2) * c);
+    }
+    const float gain = a.gain_val * (a.gain_ptr[g] ? *a.gain_ptr[g] : 1.f);
+    scale = inv * gain * c;
+  }
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e % taps;
+    const T v = from_f<T>(w[e] * scale);
+    wf[((long)t * a.O + o) * a.Ipad + i] = v;
+    if (wd) {
+      const int td = a.flip ? taps - 1 - t : t;
+      wd[((long)td * a.I + i) * a.Opad + o] = v;
+    }
+  }
+  for (int e = tid; e < (a.Ipad - a.I) * taps; e += blockDim.x) {
+    const int t = e / (a.Ipad - a.I), i = a.I + e % (a.Ipad - a.I);
+    wf[((long)t * a.O + o) * a.Ipad + i] = from_f<T>(0.f);
+  }
+}
+
+struct WprepBwdArgs {
+  const float* w_raw[HDMOE_MAX_GROUPS];
+  const float* gain_ptr[HDMOE_MAX_GROUPS];
+  const float* G[HDMOE_MAX_GROUPS];      // [tap][O][I] fp32
+  float* dw[HDMOE_MAX_GROUPS];           // (O, I, kh, kw) fp32
+  float* dgain[HDMOE_MAX_GROUPS];        // scalar accumulators (may be null)
+  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS];
+  int O, I;
+  float gain_val;
+  int normalize;
+};
+
+__global__ __launch_bounds__(128) void wprep_bwd_kernel(WprepBwdArgs a) {
+  __shared__ float sm[16];
+  const int o = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int taps = a.kh[g] * a.kw[g];
+  const int fan = a.I * taps;
+  const float* w = a.w_raw[g] + (long)o * fan;
+  const float* G = a.G[g];
+  float* dw = a.dw[g] + (long)o * fan;
+  if (!a.normalize) {
+    for (int e = tid; e < fan; e += blockDim.x) {
+      const int i = e / taps, t = e % taps;
+      dw[e] = G[((long)t * a.O + o) * a.I + i];
+    }
+    return;
+  }
+  const float c = rsqrtf((float)fan);
+  float ss = 0.f, gw = 0.f;
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e % taps;
+    const float v = w[e];
+    ss += v * v;
+    gw += v * G[((long)t * a.O + o) * a.I + i];
+  }
+  ss = block_sum(ss, sm);
+  gw = block_sum(gw, sm);
+  const float n = sqrtf(ss);
+  const float d = 1e-4f + n * c;
+  const float gain = a.gain_val * (a.gain_ptr[g] ? *a.gain_ptr[g] : 1.f);
+  const float s = gain * c;
+  const float k1 = s / d;
+  const float k2 = n > 0.f ? s * c * gw / (d * d * n) : 0.f;
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e % taps;
+    dw[e] = k1 * G[((long)t * a.O + o) * a.I + i] - k2 * w[e];
+  }
+  if (a.dgain[g] && tid == 0) atomicAdd(a.dgain[g], a.gain_val * c * gw / d);   // d/dgain of sum(G * w*gain*c/d)
+}
+
+// ------------------------------------------------------------------ conv forward / dgrad
+struct ConvArgs {
+  const void* x;      // [N][H][W][Cphys]
+  const void* w;      // [g][tap][Cout][Ipad]
+  void* y;            // [N][Ho][Wo][Cstore]
+  const void* res;    // optional [N][Ho][Wo][Cstore]:  y = alpha*acc + beta*res
+  const int* seg;     // [ngroups+1] row offsets or null
+  long wstride;
+  int N, H, W, Ho, Wo, Cin, Cphys, Ipad, Cout, Cstore, stride, ones, ngroups;
+  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
+  float alpha, beta;
+};
+
+DEVI int find_group(const int* seg, int ngroups, int n) {
+  if (!seg) return 0;
+  int g = -1;
+  for (int i = 0; i < ngroups; ++i)
+    if (n >= seg[i] && n < seg[i + 1]) g = i;
+  return g;
+}
+
+template <typename T, bool VEC>
+DEVI void load_act8(Frag8<T>& f, const T* px, int c, int Cphys, bool inb, int ones) {
+  // 8 channels c..c+7 of one pixel; channel Cphys is the implicit ones channel when `ones`
+  if (VEC) {
+    if (inb && c + 8 <= Cphys) { load8(f, px + c); return; }
+  }
+  f.zero();
+  if (!inb) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int cc = c + j;
+    if (cc < Cphys) f.set(j, to_f(px[cc]));
+    else if (ones && cc == Cphys) f.set(j, 1.f);
+  }
+}
+
+template <typename T, int NB, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int g = find_group(a.seg, a.ngroups, n);
+  if (g < 0) return;
+  const int HWo = a.Ho * a.Wo;
+  const int p0 = (blockIdx.x * 4 + wave) * 32;
+  if (p0 >= HWo) return;
+  const int nbase = blockIdx.z * (32 * NB);
+  const int p = p0 + r;
+  const bool pvalid = p < HWo;
+  const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
+  const int kh = a.kh[g], kw = a.kw[g];
+  const T* x = (const T*)a.x + (long)n * a.H * a.W * a.Cphys;
+  const T* w = (const T*)a.w + (long)g * a.wstride;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = (f32x16)(0.f);
+
+  for (int ky = 0; ky < kh; ++ky) {
+    const int iy = oy * a.stride + ky - a.pt[g];
+    for (int kx = 0; kx < kw; ++kx) {
+      const int ix = ox * a.stride + kx - a.pl[g];
+      const bool inb = pvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const T* px = x + ((long)iy * a.W + ix) * a.Cphys;
+      const T* wt = w + (long)(ky * kw + kx) * a.Cout * a.Ipad;
+      for (int c0 = 0; c0 < a.Ipad; c0 += 16) {
+        Frag8<T> fa;
+        load_act8<T, VEC>(fa, px, c0 + 8 * h, a.Cphys, inb, a.ones);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int co = nbase + 32 * b + r;
+          Frag8<T> fb;
+          if (co < a.Cout) load8(fb, wt + (long)co * a.Ipad + c0 + 8 * h);
+          else fb.zero();
+          mma32(acc[b], fa, fb);
+        }
+      }
+    }
+  }
+  T* y = (T*)a.y + (long)n * HWo * a.Cstore;
+  const T* res = a.res ? (const T*)a.res + (long)n * HWo * a.Cstore : nullptr;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int co = nbase + 32 * b + r;
+    if (co >= a.Cstore) continue;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int pp = p0 + acc_row(reg, lane);
+      if (pp < HWo) {
+        float v = a.alpha * acc[b][reg];
+        if (res) v += a.beta * to_f(res[(long)pp * a.Cstore + co]);
+        y[(long)pp * a.Cstore + co] = from_f<T>(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  const void* x;       // [N][H][W][Cphys]
+  const void* dy;      // [N][Ho][Wo][Cout]
+  float* G[HDMOE_MAX_GROUPS];   // [tap][Cout][Cin] fp32, pre-zeroed
+  const int* seg;
+  int N, H, W, Ho, Wo, Cin, Cphys, Cout, stride, ones, ngroups, spw, ob_count, ib_count;
+  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
+};
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<float> { static constexpr int CPL = 1; };
+template <> struct WgTraits<bf16> { static constexpr int CPL = 2; };   // a lane owns a channel pair (one dword)
+
+template <typename T, int CPL>
+DEVI void flush_wgrad(f32x16 (&acc)[CPL][CPL], float* G, int tap, int o0, int i0, int Cout, int Cin, int lane) {
+  const int col = lane & 31;
+#pragma unroll
+  for (int qa = 0; qa < CPL; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < CPL; ++qb) {
+      const int ci = i0 + CPL * col + qb;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int o = o0 + CPL * acc_row(reg, lane) + qa;
+        if (o < Cout && ci < Cin) atomicAdd(&G[((long)tap * Cout + o) * Cin + ci], acc[qa][qb][reg]);
+      }
+      acc[qa][qb] = (f32x16)(0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int CPL = WgTraits<T>::CPL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int t = blockIdx.x;
+  const int ib = t % a.ib_count; t /= a.ib_count;
+  const int ob = t % a.ob_count; t /= a.ob_count;
+  const int tap = t;
+  const int o0 = ob * 32 * CPL, i0 = ib * 32 * CPL;
+  const int n_begin = (blockIdx.y * 4 + wave) * a.spw;
+  const int HWo = a.Ho * a.Wo;
+  const T* X = (const T*)a.x;
+  const T* DY = (const T*)a.dy;
+
+  f32x16 acc[CPL][CPL];
+#pragma unroll
+  for (int qa = 0; qa < CPL; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < CPL; ++qb) acc[qa][qb] = (f32x16)(0.f);
+
+  int cur_g = -1;
+  for (int s = 0; s < a.spw; ++s) {
+    const int n = n_begin + s;
+    if (n >= a.N) break;
+    const int g = find_group(a.seg, a.ngroups, n);
+    if (g != cur_g) {
+      if (cur_g >= 0 && tap < a.kh[cur_g] * a.kw[cur_g])
+        flush_wgrad<T, CPL>(acc, a.G[cur_g], tap, o0, i0, a.Cout, a.Cin, lane);
+      cur_g = g;
+    }
+    if (g < 0 || tap >= a.kh[g] * a.kw[g]) continue;
+    const int ky = tap / a.kw[g] - a.pt[g], kx = tap % a.kw[g] - a.pl[g];
+    const T* dy = DY + (long)n * HWo * a.Cout;
+    const T* x = X + (long)n * a.H * a.W * a.Cphys;
+    for (int p0 = 0; p0 < HWo; p0 += 16) {
+      Frag8<T> fa[CPL], fb[CPL];
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) { fa[q].zero(); fb[q].zero(); }
+      int p = p0 + 8 * h;
+      int oy = p / a.Wo, ox = p % a.Wo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (p < HWo) {
+          const int iy = oy * a.stride + ky, ix = ox * a.stride + kx;
+          const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          const T* dyp = dy + (long)p * a.Cout;
+          const T* xp = x + ((long)iy * a.W + ix) * a.Cphys;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const int o = o0 + CPL * r + q;
+            if (o < a.Cout) fa[q].set(j, to_f(dyp[o]));
+            const int ci = i0 + CPL * r + q;
+            if (inb) {
+              if (ci < a.Cphys) fb[q].set(j, to_f(xp[ci]));
+              else if (a.ones && ci == a.Cphys) fb[q].set(j, 1.f);
+            }
+          }
+        }
+        ++p; ++ox;
+        if (ox == a.Wo) { ox = 0; ++oy; }
+      }
+#pragma unroll
+      for (int qa = 0; qa < CPL; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < CPL; ++qb) mma32(acc[qa][qb], fa[qa], fb[qb]);
+    }
+  }
+  if (cur_g >= 0 && tap < a.kh[cur_g] * a.kw[cur_g])
+    flush_wgrad<T, CPL>(acc, a.G[cur_g], tap, o0, i0, a.Cout, a.Cin, lane);
+}
+
+template <typename T, int NB>
+void launch_conv(const ConvArgs& a, bool vec, hipStream_t st) {
+  dim3 grid(cdiv((long)a.Ho * a.Wo, 128), a.N, cdiv(a.Cstore, 32 * NB));
+  if (vec) hipLaunchKernelGGL((conv_fwd_kernel<T, NB, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_fwd_kernel<T, NB, false>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T>
+void launch_conv_nb(const ConvArgs& a, bool vec, hipStream_t st) {
+  if (a.Cstore <= 32) launch_conv<T, 1>(a, vec, st);
+  else if (a.Cstore <= 64) launch_conv<T, 2>(a, vec, st);
+  else launch_conv<T, 4>(a, vec, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdmoe_wprep_fwd(float* const* w_raw, const float* const* gain_ptr, float gain_val, const int* kh,
+                    const int* kw, int ngroups, int O, int I, int Ipad, int Opad, void* wf, long wf_stride,
+                    void* wd, long wd_stride, int normalize, int mutate, int flip, int dtype,
+                    hipStream_t stream) {
+  if (ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || O < 1 || I < 1 || Ipad < I || Ipad % 16 || !wf) return HDMOE_EINVAL;
+  if (wd && (Opad < O || Opad % 16)) return HDMOE_EINVAL;
+  WprepArgs a;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    a.w_raw[g] = w_raw[s]; a.gain_ptr[g] = gain_ptr ? gain_ptr[s] : nullptr;
+    a.kh[g] = kh[s]; a.kw[g] = kw[s];
+  }
+  a.wf = wf; a.wd = wd; a.wf_stride = wf_stride; a.wd_stride = wd_stride;
+  a.O = O; a.I = I; a.Ipad = Ipad; a.Opad = wd ? Opad : O; a.gain_val = gain_val;
+  a.normalize = normalize; a.mutate = mutate; a.flip = flip;
+  dim3 grid(wd ? (Opad > O ? Opad : O) : O, ngroups);
+  if (dtype == HDMOE_F32) hipLaunchKernelGGL(wprep_fwd_kernel<float>, grid, dim3(128), 0, stream, a);
+  else if (dtype == HDMOE_BF16) hipLaunchKernelGGL(wprep_fwd_kernel<bf16>, grid, dim3(128), 0, stream, a);
+  else return HDMOE_EDTYPE;
+  return hdmoe_launch_status();
+}
+
+int hdmoe_wprep_bwd(const float* const* w_raw, const float* const* gain_ptr, float gain_val,
+                    const float* const* G, float* const* dw, float* const* dgain, const int* kh, const int* kw,
+                    int ngroups, int O, int I, int normalize, hipStream_t stream) {
+  if (ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || O < 1 || I < 1) return HDMOE_EINVAL;
+  WprepBwdArgs a;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    a.w_raw[g] = w_raw[s]; a.gain_ptr[g] = gain_ptr ? gain_ptr[s] : nullptr;
+    a.G[g] = G[s]; a.dw[g] = dw[s]; a.dgain[g] = dgain ? dgain[s] : nullptr;
+    a.kh[g] = kh[s]; a.kw[g] = kw[s];
+  }
+  a.O = O; a.I = I; a.gain_val = gain_val; a.normalize = normalize;
+  hipLaunchKernelGGL(wprep_bwd_kernel, dim3(O, ngroups), dim3(128), 0, stream, a);
+  return hdmoe_launch_status();
+}
+
+int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float alpha, float beta,
+                   const int* seg, int ngroups, long wstride, int N, int H, int W, int Ho, int Wo, int Cin,
+                   int Cphys, int Ipad, int Cout, int Cstore, int stride, int ones, const int* kh, const int* kw,
+                   const int* pt, const int* pl, int dtype, hipStream_t stream) {
+  if (!x || !w || !y || N < 0 || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return HDMOE_EINVAL;
+  if (Ipad % 16 || Ipad < Cin || Cin != Cphys + (ones ? 1 : 0) || Cstore > Cout || stride < 1) return HDMOE_EINVAL;
+  if (N == 0 || Ho * Wo == 0) return HDMOE_OK;
+  if (N > 65535) return HDMOE_EINVAL;
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.res = res; a.seg = seg; a.wstride = wstride;
+  a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cphys = Cphys; a.Ipad = Ipad; a.Cout = Cout;
+  a.Cstore = Cstore; a.stride = stride; a.ones = ones; a.ngroups = ngroups; a.alpha = alpha; a.beta = beta;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
+  }
+  if (dtype == HDMOE_F32) launch_conv_nb<float>(a, Cphys % 4 == 0 && ((uintptr_t)x % 16 == 0), stream);
+  else if (dtype == HDMOE_BF16) launch_conv_nb<bf16>(a, Cphys % 8 == 0 && ((uintptr_t)x % 16 == 0), stream);
+  else return HDMOE_EDTYPE;
+  return hdmoe_launch_status();
+}
+
+int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H,
+                     int W, int Ho, int Wo, int Cin, int Cphys, int Cout, int stride, int ones, const int* kh,
+                     const int* kw, const int* pt, const int* pl, int dtype, hipStream_t stream) {
+  if (!x || !dy || !G || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || Cin != Cphys + (ones ? 1 : 0)) return HDMOE_EINVAL;
+  if (N == 0 || Ho * Wo == 0) return HDMOE_OK;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cphys = Cphys;
+  a.Cout = Cout; a.stride = stride; a.ones = ones; a.ngroups = ngroups;
+  int maxtaps = 0;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    a.G[g] = G[s]; a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
+    if (kh[s] * kw[s] > maxtaps) maxtaps = kh[s] * kw[s];
+  }
+  const int cpl = dtype == HDMOE_BF16 ? 2 : 1;
+  a.ob_count = cdiv(Cout, 32 * cpl);
+  a.ib_count = cdiv(Cin, 32 * cpl);
+  const long tiles = (long)maxtaps * a.ob_count * a.ib_count;
+  // samples per wave: keep >= ~2048 waves in flight, but at least 1 and at most 16 samples per wave
+  long spw = ((long)N * tiles) / 2048;
+  if (spw < 1) spw = 1;
+  if (spw > 16) spw = 16;
+  a.spw = (int)spw;
+  dim3 grid((unsigned)tiles, cdiv(N, 4 * spw));
+  if (dtype == HDMOE_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, stream, a);
+  else if (dtype == HDMOE_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16>, grid, dim3(256), 0, stream, a);
+  else return HDMOE_EDTYPE;
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,584 @@
+// K4 / K7: HBM-bound pointwise, broadcast and relayout kernels of the HDMOE hot path (fwd + bwd).
+// All activation tensors are NHWC / [rows][C]; "vector path" tensors ((B,F) embeddings, per-sample
+// scalars) are always fp32.  Grid-stride loops, <= 2048 workgroups of 256 threads (guide G11).
+#include "common.h"
+#include "hdmoe.h"
+
+namespace {
+
+constexpr int TPB = 256;
+static inline unsigned grid_for(long n) {
+  long b = (n + TPB - 1) / TPB;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- generic pointwise
+template <typename T>
+__global__ void axpby_kernel(T* out, const T* x, const T* y, float a, float b, long n) {
+  GRID_STRIDE(i, n) {
+    float v = a * to_f(x[i]);
+    if (y) v += b * to_f(y[i]);
+    out[i] = from_f<T>(v);
+  }
+}
+template <typename T>
+__global__ void affine_kernel(T* out, const T* x, float a, float c, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<T>(a * to_f(x[i]) + c);
+}
+template <typename T>
+__global__ void mul_kernel(T* out, const T* x, const T* y, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<T>(to_f(x[i]) * to_f(y[i]));
+}
+template <typename TI, typename TO>
+__global__ void cast_kernel(TO* out, const TI* x, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<TO>(to_f(x[i]));
+}
+template <typename T>
+__global__ void mp_silu_fwd_kernel(T* out, const T* x, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<T>(mp_silu_f(to_f(x[i])));
+}
+template <typename T>
+__global__ void mp_silu_bwd_kernel(T* dx, const T* dy, const T* x, long n) {
+  GRID_STRIDE(i, n) dx[i] = from_f<T>(to_f(dy[i]) * mp_silu_grad_f(to_f(x[i])));
+}
+template <typename T>
+__global__ void sigmoid_fwd_kernel(T* out, const T* x, float a, long n) {   // sigmoid(a*x)
+  GRID_STRIDE(i, n) out[i] = from_f<T>(1.f / (1.f + __expf(-a * to_f(x[i]))));
+}
+template <typename T>
+__global__ void sigmoid_bwd_kernel(T* dx, const T* dy, const T* y, float a, long n) {
+  GRID_STRIDE(i, n) { const float s = to_f(y[i]); dx[i] = from_f<T>(to_f(dy[i]) * a * s * (1.f - s)); }
+}
+
+// ---------------------------------------------------------------- FiLM + mp_silu   (Unet_block, model_components.py:242-243)
+template <typename T>
+__global__ void film_silu_fwd_kernel(T* out, const T* u, const float* e, long HW, int C, long n) {
+  GRID_STRIDE(i, n) {
+    const long row = i / C; const int c = (int)(i - row * C);
+    const long s = row / HW;
+    out[i] = from_f<T>(mp_silu_f(to_f(u[i]) * e[s * C + c]));
+  }
+}
+// one block per (pixel chunk, sample): du = da*silu'(u*e)*e ; de[n,c] += sum_pix da*silu'(u*e)*u
+template <typename T>
+__global__ void film_silu_bwd_kernel(T* du, float* de, const T* da, const T* u, const float* e, long HW, int C, int chunk) {
+  extern __shared__ float sm[];
+  const int s = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+  const long base = (long)s * HW * C;
+  for (long i = p0 * C + threadIdx.x; i < p1 * C; i += blockDim.x) {
+    const int c = (int)(i % C);
+    const float ev = e[(long)s * C + c], uv = to_f(u[base + i]);
+    const float g = to_f(da[base + i]) * mp_silu_grad_f(uv * ev);
+    du[base + i] = from_f<T>(g * ev);
+    atomicAdd(&sm[c], g * uv);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&de[(long)s * C + c], sm[c]);
+}
+
+// ---------------------------------------------------------------- per-sample scalar scale
+template <typename T>
+__global__ void scale_rows_fwd_kernel(T* out, const T* x, const float* s, long L, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<T>(to_f(x[i]) * s[i / L]);
+}
+template <typename T>
+__global__ void scale_rows_bwd_kernel(T* dx, float* ds, const T* dy, const T* x, const float* s, long L, int chunk) {
+  __shared__ float sm[16];
+  const int r = blockIdx.y;
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < L) ? p0 + chunk : L;
+  const float sv = s[r];
+  float acc = 0.f;
+  for (long i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+    const float g = to_f(dy[(long)r * L + i]);
+    if (dx) dx[(long)r * L + i] = from_f<T>(g * sv);
+    if (ds) acc += g * to_f(x[(long)r * L + i]);
+  }
+  if (ds) {
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(&ds[r], acc);
+  }
+}
+
+// ---------------------------------------------------------------- mp_cat  (model_internals.py:69-92)
+template <typename T>
+__global__ void cat2_fwd_kernel(T* out, const T* a, const T* b, float wa, float wb, int Ca, int Cb, long rows) {
+  const int C = Ca + Cb;
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    out[i] = from_f<T>(c < Ca ? wa * to_f(a[r * Ca + c]) : wb * to_f(b[r * Cb + c - Ca]));
+  }
+}
+template <typename T>
+__global__ void cat2_bwd_kernel(T* da, T* db, const T* dout, float wa, float wb, int Ca, int Cb, long rows) {
+  const int C = Ca + Cb;
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    const float g = to_f(dout[i]);
+    if (c < Ca) da[r * Ca + c] = from_f<T>(wa * g);
+    else db[r * Cb + c - Ca] = from_f<T>(wb * g);
+  }
+}
+
+// ---------------------------------------------------------------- resample (model_internals.py:95-127)
+template <typename T>   // out[n][h][w][c] = scale * sum_{2x2} x[n][2h+i][2w+j][c]
+__global__ void pool2_kernel(T* out, const T* x, int Ho, int Wo, int C, float scale, long n) {
+  GRID_STRIDE(i, n) {
+    long t = i; const int c = (int)(t % C); t /= C;
+    const int w = (int)(t % Wo); t /= Wo;
+    const int h = (int)(t % Ho); const long s = t / Ho;
+    const T* p = x + (((s * 2 * Ho + 2 * h) * 2 * Wo) + 2 * w) * C + c;
+    const long rs = (long)2 * Wo * C;
+    out[i] = from_f<T>(scale * (to_f(p[0]) + to_f(p[C]) + to_f(p[rs]) + to_f(p[rs + C])));
+  }
+}
+template <typename T>   // out[n][h][w][c] = scale * x[n][h/2][w/2][c]
+__global__ void upsample2_kernel(T* out, const T* x, int Ho, int Wo, int C, float scale, long n) {
+  GRID_STRIDE(i, n) {
+    long t = i; const int c = (int)(t % C); t /= C;
+    const int w = (int)(t % Wo); t /= Wo;
+    const int h = (int)(t % Ho); const long s = t / Ho;
+    out[i] = from_f<T>(scale * to_f(x[((s * (Ho / 2) + h / 2) * (Wo / 2) + w / 2) * C + c]));
+  }
+}
+
+// ---------------------------------------------------------------- sequence reduce / broadcast  ([N][S][C] <-> fp32 [N][C])
+template <typename T>
+__global__ void seq_reduce_kernel(float* out, const T* x, long S, int C, float scale, int chunk) {
+  extern __shared__ float sm[];
+  const int s = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < S) ? p0 + chunk : S;
+  const long base = (long)s * S * C;
+  for (long i = p0 * C + threadIdx.x; i < p1 * C; i += blockDim.x) atomicAdd(&sm[i % C], to_f(x[base + i]));
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(long)s * C + c], scale * sm[c]);
+}
+template <typename T>   // out = (x ? x : 0) + scale * t[n][c]
+__global__ void seq_bcast_add_kernel(T* out, const T* x, const float* t, long S, int C, float scale, long n) {
+  GRID_STRIDE(i, n) {
+    const long row = i / C; const int c = (int)(i - row * C);
+    const float v = scale * t[(row / S) * C + c];
+    out[i] = from_f<T>(x ? to_f(x[i]) + v : v);
+  }
+}
+// out[r][i] = x[r][i] + bias[i]   /   colsum: dbias[i] += sum_r dy[r][i]
+template <typename T>
+__global__ void bias_add_kernel(T* out, const T* x, const float* bias, long L, long n) {
+  GRID_STRIDE(i, n) out[i] = from_f<T>(to_f(x[i]) + bias[i % L]);
+}
+template <typename T>
+__global__ void colsum_kernel(float* out, const T* dy, long rows, long L, int rchunk) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const long r0 = (long)blockIdx.y * rchunk;
+  const long r1 = (r0 + rchunk < rows) ? r0 + rchunk : rows;
+  float acc = 0.f;
+  for (long r = r0; r < r1; ++r) acc += to_f(dy[r * L + i]);
+  atomicAdd(&out[i], acc);
+}
+
+// ---------------------------------------------------------------- lerp with a learnable scalar  (model_config2.py:291)
+template <typename T>
+__global__ void lerp_param_fwd_kernel(T* out, const T* a, const T* b, const float* alpha, long n) {
+  const float al = *alpha;
+  GRID_STRIDE(i, n) { const float av = to_f(a[i]); out[i] = from_f<T>(av + al * (to_f(b[i]) - av)); }
+}
+template <typename T>
+__global__ void lerp_param_bwd_kernel(T* da, T* db, float* dalpha, const T* g, const T* a, const T* b, const float* alpha, long n) {
+  __shared__ float sm[16];
+  const float al = *alpha;
+  float acc = 0.f;
+  GRID_STRIDE(i, n) {
+    const float gv = to_f(g[i]);
+    da[i] = from_f<T>((1.f - al) * gv);
+    db[i] = from_f<T>(al * gv);
+    acc += gv * (to_f(b[i]) - to_f(a[i]));
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(dalpha, acc);
+}
+
+// ---------------------------------------------------------------- output gate  (model_config2.py:297-301)
+// g = softmax(logits[.,2]); mixed = g0*U + g1*A; out = ((1-t)*U + t*mixed)/sqrt((1-t)^2+t^2), t = 0.5
+template <typename T>
+__global__ void gate_mix_fwd_kernel(T* out, float* gate, const T* logits, const T* U, const T* A, int C, long rows) {
+  const float k = 0.70710678118654752f;   // 0.5 / sqrt(0.5)
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    const float l0 = to_f(logits[2 * r]), l1 = to_f(logits[2 * r + 1]);
+    const float m = fmaxf(l0, l1);
+    const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+    if (c == 0) { gate[2 * r] = g0; gate[2 * r + 1] = g1; }
+    const float u = to_f(U[i]), a = to_f(A[i]);
+    out[i] = from_f<T>(k * (u + g0 * u + g1 * a));
+  }
+}
+// one thread per pixel row
+template <typename T>
+__global__ void gate_mix_bwd_kernel(T* dU, T* dA, T* dlogits, const T* dout, const float* dgate, const float* gate,
+                                    const T* U, const T* A, int C, long rows) {
+  const float k = 0.70710678118654752f;
+  GRID_STRIDE(r, rows) {
+    const float g0 = gate[2 * r], g1 = gate[2 * r + 1];
+    float d0 = dgate ? dgate[2 * r] : 0.f, d1 = dgate ? dgate[2 * r + 1] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      const long i = r * C + c;
+      const float go = k * to_f(dout[i]);
+      const float u = to_f(U[i]), a = to_f(A[i]);
+      dU[i] = from_f<T>(go * (1.f + g0));
+      dA[i] = from_f<T>(go * g1);
+      d0 += go * u; d1 += go * a;
+    }
+    const float dot = d0 * g0 + d1 * g1;
+    dlogits[2 * r] = from_f<T>(g0 * (d0 - dot));
+    dlogits[2 * r + 1] = from_f<T>(g1 * (d1 - dot));
+  }
+}
+
+// ---------------------------------------------------------------- row softmax for tiny C (Scaling_router, model_components.py:64)
+__global__ void softmax_rows_fwd_kernel(float* out, const float* x, int C, float scale, long rows) {
+  GRID_STRIDE(r, rows) {
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, x[r * C + c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += __expf(x[r * C + c] - m);
+    for (int c = 0; c < C; ++c) out[r * C + c] = scale * __expf(x[r * C + c] - m) / s;
+  }
+}
+__global__ void softmax_rows_bwd_kernel(float* dx, const float* dy, const float* y, int C, float scale, long rows) {
+  GRID_STRIDE(r, rows) {    // y = scale * p
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += dy[r * C + c] * y[r * C + c];
+    for (int c = 0; c < C; ++c) dx[r * C + c] = y[r * C + c] * (dy[r * C + c] - dot / scale);
+  }
+}
+
+// ---------------------------------------------------------------- layout: NCHW fp32 <-> NHWC T with per-sample scale
+template <typename T>   // out_nhwc[n][p][c] = s[n] * x_nchw[n][c][p]
+__global__ void nchw_to_nhwc_kernel(T* out, const float* x, const float* s, int C, long HW, long n) {
+  GRID_STRIDE(i, n) {
+    long t = i; const int c = (int)(t % C); t /= C;
+    const long p = t % HW; const long b = t / HW;
+    const float v = x[(b * C + c) * HW + p];
+    out[i] = from_f<T>(s ? v * s[b] : v);
+  }
+}
+template <typename T>   // out_nchw = sf[n]*F_nhwc + (x ? sx[n]*x_nchw : 0)
+__global__ void nhwc_to_nchw_kernel(float* out, const T* F, const float* sf, const float* x, const float* sx, int C, long HW, long n) {
+  GRID_STRIDE(i, n) {
+    long t = i; const long p = t % HW; t /= HW;
+    const int c = (int)(t % C); const long b = t / C;
+    float v = to_f(F[(b * HW + p) * C + c]);
+    if (sf) v *= sf[b];
+    if (x) v += (sx ? sx[b] : 1.f) * x[i];
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- patch <-> image relayout (Vit_expert, model_components.py:698-704)
+// tok[b][(hp,wp)][f] <-> img[b][hp*p+i][wp*p+j][c];  order 0: f = (i*p+j)*C + c ;  order 1 (PixelShuffle): f = c*p*p + i*p + j
+template <typename T, bool TO_IMG>
+__global__ void patch_relayout_kernel(T* out, const T* in, int H, int W, int C, int p, int hp, int wp, int order, long n) {
+  // iterates over image elements of the *padded-free* image (H x W); tokens cover hp*p x wp*p
+  GRID_STRIDE(i, n) {
+    long t = i; const int c = (int)(t % C); t /= C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const long b = t / H;
+    const int ph = y / p, ii = y % p, pw = x / p, jj = x % p;
+    const int f = order ? c * p * p + ii * p + jj : (ii * p + jj) * C + c;
+    const long tk = ((b * hp + ph) * wp + pw) * ((long)C * p * p) + f;
+    if (TO_IMG) out[i] = in[tk];
+    else out[tk] = in[i];
+  }
+}
+
+// ---------------------------------------------------------------- small vector-path kernels
+__global__ void fourier_kernel(float* out, const float* x, const float* freqs, const float* phases, int F, long n) {
+  GRID_STRIDE(i, n) {                                                  // model_internals.py:171-174
+    const long b = i / F; const int f = (int)(i - b * F);
+    out[i] = cosf(x[b] * freqs[f] + phases[f]) * 1.41421356237309515f;
+  }
+}
+// EDM preconditioning coefficients (model_config2.py:431-438): coef[0..3][B] = c_skip, c_out, c_in, c_noise
+__global__ void edm_coeffs_kernel(float* coef, const float* sigma, int nsig, float sd, int B) {
+  GRID_STRIDE(b, B) {
+    const float s = sigma[nsig == 1 ? 0 : b];
+    const float q = s * s + sd * sd;
+    coef[b] = sd * sd / q;
+    coef[B + b] = s * sd / sqrtf(q);
+    coef[2 * B + b] = 1.f / sqrtf(q);
+    coef[3 * B + b] = logf(s) * 0.25f;
+  }
+}
+// closed-form path scaling (model_config2.py:244-249): out[0][B]=s_vit, out[1][B]=s_unet, pair[B][2]
+__global__ void sigmoid_scaling_kernel(float* sv, float* su, float* pair, const float* c_noise, float tp, float soft, int B) {
+  GRID_STRIDE(b, B) {
+    const float w = 1.f / (1.f + expf(-((c_noise[b] * 4.f - tp) / soft)));
+    const float v = (w + 1e-2f) * 2.f, u = ((1.f - w) + 1e-2f) * 2.f;
+    sv[b] = v; su[b] = u; pair[2 * b] = v; pair[2 * b + 1] = u;
+  }
+}
+
+
+// ---------------------------------------------------------------- adaLN (Router, model_components.py:148-151): x*(1+gamma)+beta, cond = [gamma | beta]
+__global__ void adaln_fwd_kernel(float* out, const float* x, const float* cond, int F, long n) {
+  GRID_STRIDE(i, n) {
+    const long b = i / F; const int f = (int)(i - b * F);
+    out[i] = x[i] * (1.f + cond[b * 2 * F + f]) + cond[b * 2 * F + F + f];
+  }
+}
+__global__ void adaln_bwd_kernel(float* dx, float* dcond, const float* g, const float* x, const float* cond, int F, long n) {
+  GRID_STRIDE(i, n) {
+    const long b = i / F; const int f = (int)(i - b * F);
+    dx[i] = g[i] * (1.f + cond[b * 2 * F + f]);
+    dcond[b * 2 * F + f] = g[i] * x[i];
+    dcond[b * 2 * F + F + f] = g[i];
+  }
+}
+// positive part of one column of the sparse gate matrix: out[b] = w[b][e] > 0 ? w[b][e] : 0   (NaN -> 0, as `mask = w > 0`)
+__global__ void take_col_pos_fwd_kernel(float* out, const float* w, int E, int e, long B) {
+  GRID_STRIDE(b, B) { const float v = w[b * E + e]; out[b] = v > 0.f ? v : 0.f; }
+}
+__global__ void take_col_pos_bwd_kernel(float* dw, const float* g, const float* w, int E, int e, long B) {
+  GRID_STRIDE(b, B) { if (w[b * E + e] > 0.f) dw[b * E + e] = g[b]; }
+}
+
+// ---------------------------------------------------------------- counter RNG (Philox4x32-10)
+DEVI void philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
+  uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+}
+DEVI float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.f / 16777216.f); }
+
+// F.dropout(p): keep with prob 1-p, scale 1/(1-p); the mask is regenerated from (seed, element index) in bwd
+template <typename T>
+__global__ void dropout_kernel(T* out, const T* x, uint32_t seed_lo, uint32_t seed_hi, float p, long n) {
+  const float inv = 1.f / (1.f - p);
+  GRID_STRIDE(q, (n + 3) / 4) {
+    uint32_t r[4];
+    philox((uint32_t)q, (uint32_t)(q >> 32), seed_lo, seed_hi, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = q * 4 + j;
+      if (i < n) out[i] = from_f<T>(u01(r[j]) >= p ? to_f(x[i]) * inv : 0.f);
+    }
+  }
+}
+__global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, float scale, long n) {
+  GRID_STRIDE(q, (n + 3) / 4) {
+    uint32_t r[4];
+    philox((uint32_t)q, (uint32_t)(q >> 32), seed_lo, seed_hi, r);
+    const float a0 = sqrtf(-2.f * logf(u01(r[0]))), a1 = sqrtf(-2.f * logf(u01(r[2])));
+    const float t0 = 6.28318530717958648f * u01(r[1]), t1 = 6.28318530717958648f * u01(r[3]);
+    const float v[4] = {a0 * cosf(t0), a0 * sinf(t0), a1 * cosf(t1), a1 * sinf(t1)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (q * 4 + j < n) out[q * 4 + j] = scale * v[j];
+  }
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, CALL)                    \
+  if ((dtype) == HDMOE_F32) { using T = float; CALL; }   \
+  else if ((dtype) == HDMOE_BF16) { using T = bf16; CALL; } \
+  else return HDMOE_EDTYPE;                       \
+  return hdmoe_launch_status();
+
+#define L1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, __VA_ARGS__)
+
+extern "C" {
+
+int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
+}
+int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(affine_kernel<T>, n, (T*)out, (const T*)x, a, c, n))
+}
+int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(mul_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, n))
+}
+int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, hipStream_t stream) {
+  if (dt_in == HDMOE_F32 && dt_out == HDMOE_BF16) L1D((cast_kernel<float, bf16>), n, (bf16*)out, (const float*)x, n);
+  else if (dt_in == HDMOE_BF16 && dt_out == HDMOE_F32) L1D((cast_kernel<bf16, float>), n, (float*)out, (const bf16*)x, n);
+  else if (dt_in == HDMOE_F32 && dt_out == HDMOE_F32) L1D((cast_kernel<float, float>), n, (float*)out, (const float*)x, n);
+  else if (dt_in == HDMOE_BF16 && dt_out == HDMOE_BF16) L1D((cast_kernel<bf16, bf16>), n, (bf16*)out, (const bf16*)x, n);
+  else return HDMOE_EDTYPE;
+  return hdmoe_launch_status();
+}
+int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(mp_silu_fwd_kernel<T>, n, (T*)out, (const T*)x, n))
+}
+int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(mp_silu_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)x, n))
+}
+int hdmoe_sigmoid_fwd(void* out, const void* x, float a, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(sigmoid_fwd_kernel<T>, n, (T*)out, (const T*)x, a, n))
+}
+int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(sigmoid_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)y, a, n))
+}
+int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, hipStream_t stream) {
+  const long n = (long)N * HW * C;
+  DT_SWITCH(dtype, L1D(film_silu_fwd_kernel<T>, n, (T*)out, (const T*)u, e, HW, C, n))
+}
+int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
+                        int dtype, hipStream_t stream) {
+  if (N > 65535) return HDMOE_EINVAL;
+  const int chunk = 256;
+  dim3 grid(cdiv(HW, chunk), N);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(film_silu_bwd_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de,
+                                      (const T*)da, (const T*)u, e, HW, C, chunk))
+}
+int hdmoe_scale_rows_fwd(void* out, const void* x, const float* s, long rows, long L, int dtype, hipStream_t stream) {
+  const long n = rows * L;
+  DT_SWITCH(dtype, L1D(scale_rows_fwd_kernel<T>, n, (T*)out, (const T*)x, s, L, n))
+}
+int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, const float* s, long rows, long L,
+                         int dtype, hipStream_t stream) {
+  if (rows > 65535) return HDMOE_EINVAL;
+  const int chunk = 8192;
+  dim3 grid(cdiv(L, chunk), (unsigned)rows);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(scale_rows_bwd_kernel<T>, grid, dim3(TPB), 0, stream, (T*)dx, ds, (const T*)dy,
+                                      (const T*)x, s, L, chunk))
+}
+int hdmoe_cat2_fwd(void* out, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows, int dtype,
+                   hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(cat2_fwd_kernel<T>, rows * (Ca + Cb), (T*)out, (const T*)a, (const T*)b, wa, wb, Ca, Cb, rows))
+}
+int hdmoe_cat2_bwd(void* da, void* db, const void* dout, float wa, float wb, int Ca, int Cb, long rows, int dtype,
+                   hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(cat2_bwd_kernel<T>, rows * (Ca + Cb), (T*)da, (T*)db, (const T*)dout, wa, wb, Ca, Cb, rows))
+}
+int hdmoe_pool2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, hipStream_t stream) {
+  const long n = (long)N * Ho * Wo * C;
+  DT_SWITCH(dtype, L1D(pool2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
+}
+int hdmoe_upsample2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, hipStream_t stream) {
+  if ((Ho | Wo) & 1) return HDMOE_EINVAL;
+  const long n = (long)N * Ho * Wo * C;
+  DT_SWITCH(dtype, L1D(upsample2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
+}
+int hdmoe_seq_reduce(float* out, const void* x, int N, long S, int C, float scale, int dtype, hipStream_t stream) {
+  if (N > 65535 || C > 8192) return HDMOE_EINVAL;
+  const int chunk = 64;
+  dim3 grid(cdiv(S, chunk), N);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(seq_reduce_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x,
+                                      S, C, scale, chunk))
+}
+int hdmoe_seq_bcast_add(void* out, const void* x, const float* t, int N, long S, int C, float scale, int dtype,
+                        hipStream_t stream) {
+  const long n = (long)N * S * C;
+  DT_SWITCH(dtype, L1D(seq_bcast_add_kernel<T>, n, (T*)out, (const T*)x, t, S, C, scale, n))
+}
+int hdmoe_bias_add(void* out, const void* x, const float* bias, long rows, long L, int dtype, hipStream_t stream) {
+  const long n = rows * L;
+  DT_SWITCH(dtype, L1D(bias_add_kernel<T>, n, (T*)out, (const T*)x, bias, L, n))
+}
+int hdmoe_colsum(float* out, const void* dy, long rows, long L, int dtype, hipStream_t stream) {
+  const int rchunk = 64;
+  if (cdiv(rows, rchunk) > 65535) return HDMOE_EINVAL;
+  dim3 grid(cdiv(L, TPB), cdiv(rows, rchunk));
+  DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(TPB), 0, stream, out, (const T*)dy, rows, L, rchunk))
+}
+int hdmoe_lerp_param_fwd(void* out, const void* a, const void* b, const float* alpha, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(lerp_param_fwd_kernel<T>, n, (T*)out, (const T*)a, (const T*)b, alpha, n))
+}
+int hdmoe_lerp_param_bwd(void* da, void* db, float* dalpha, const void* g, const void* a, const void* b,
+                         const float* alpha, long n, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(lerp_param_bwd_kernel<T>, n, (T*)da, (T*)db, dalpha, (const T*)g, (const T*)a, (const T*)b, alpha, n))
+}
+int hdmoe_gate_mix_fwd(void* out, float* gate, const void* logits, const void* U, const void* A, long rows, int C,
+                       int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(gate_mix_fwd_kernel<T>, rows * C, (T*)out, gate, (const T*)logits, (const T*)U, (const T*)A, C, rows))
+}
+int hdmoe_gate_mix_bwd(void* dU, void* dA, void* dlogits, const void* dout, const float* dgate, const float* gate,
+                       const void* U, const void* A, long rows, int C, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, L1D(gate_mix_bwd_kernel<T>, rows, (T*)dU, (T*)dA, (T*)dlogits, (const T*)dout, dgate, gate,
+                       (const T*)U, (const T*)A, C, rows))
+}
+int hdmoe_softmax_rows_fwd(float* out, const float* x, long rows, int C, float scale, hipStream_t stream) {
+  L1D(softmax_rows_fwd_kernel, rows, out, x, C, scale, rows);
+  return hdmoe_launch_status();
+}
+int hdmoe_softmax_rows_bwd(float* dx, const float* dy, const float* y, long rows, int C, float scale, hipStream_t stream) {
+  L1D(softmax_rows_bwd_kernel, rows, dx, dy, y, C, scale, rows);
+  return hdmoe_launch_status();
+}
+int hdmoe_nchw_to_nhwc(void* out, const float* x, const float* s, int N, int C, long HW, int dtype, hipStream_t stream) {
+  const long n = (long)N * C * HW;
+  DT_SWITCH(dtype, L1D(nchw_to_nhwc_kernel<T>, n, (T*)out, x, s, C, HW, n))
+}
+int hdmoe_nhwc_to_nchw(float* out, const void* F, const float* sf, const float* x, const float* sx, int N, int C, long HW,
+                       int dtype, hipStream_t stream) {
+  const long n = (long)N * C * HW;
+  DT_SWITCH(dtype, L1D(nhwc_to_nchw_kernel<T>, n, out, (const T*)F, sf, x, sx, C, HW, n))
+}
+int hdmoe_patch_relayout(void* out, const void* in, int N, int H, int W, int C, int p, int hp, int wp, int order,
+                         int to_img, int dtype, hipStream_t stream) {
+  if (hp * p < H || wp * p < W) return HDMOE_EINVAL;
+  const long n = (long)N * H * W * C;
+  if (to_img) { DT_SWITCH(dtype, L1D((patch_relayout_kernel<T, true>), n, (T*)out, (const T*)in, H, W, C, p, hp, wp, order, n)) }
+  else { DT_SWITCH(dtype, L1D((patch_relayout_kernel<T, false>), n, (T*)out, (const T*)in, H, W, C, p, hp, wp, order, n)) }
+}
+int hdmoe_fourier(float* out, const float* x, const float* freqs, const float* phases, int B, int F, hipStream_t stream) {
+  const long n = (long)B * F;
+  L1D(fourier_kernel, n, out, x, freqs, phases, F, n);
+  return hdmoe_launch_status();
+}
+int hdmoe_edm_coeffs(float* coef, const float* sigma, int nsig, float sigma_data, int B, hipStream_t stream) {
+  if (nsig != 1 && nsig != B) return HDMOE_EINVAL;
+  L1D(edm_coeffs_kernel, B, coef, sigma, nsig, sigma_data, B);
+  return hdmoe_launch_status();
+}
+int hdmoe_sigmoid_scaling(float* sv, float* su, float* pair, const float* c_noise, float tp, float soft, int B,
+                          hipStream_t stream) {
+  L1D(sigmoid_scaling_kernel, B, sv, su, pair, c_noise, tp, soft, B);
+  return hdmoe_launch_status();
+}
+int hdmoe_adaln_fwd(float* out, const float* x, const float* cond, long B, int F, hipStream_t stream) {
+  L1D(adaln_fwd_kernel, B * F, out, x, cond, F, B * F);
+  return hdmoe_launch_status();
+}
+int hdmoe_adaln_bwd(float* dx, float* dcond, const float* g, const float* x, const float* cond, long B, int F, hipStream_t stream) {
+  L1D(adaln_bwd_kernel, B * F, dx, dcond, g, x, cond, F, B * F);
+  return hdmoe_launch_status();
+}
+int hdmoe_take_col_pos_fwd(float* out, const float* w, long B, int E, int e, hipStream_t stream) {
+  if (e < 0 || e >= E) return HDMOE_EINVAL;
+  L1D(take_col_pos_fwd_kernel, B, out, w, E, e, B);
+  return hdmoe_launch_status();
+}
+int hdmoe_take_col_pos_bwd(float* dw, const float* g, const float* w, long B, int E, int e, hipStream_t stream) {
+  if (e < 0 || e >= E) return HDMOE_EINVAL;
+  L1D(take_col_pos_bwd_kernel, B, dw, g, w, E, e, B);
+  return hdmoe_launch_status();
+}
+int hdmoe_dropout(void* out, const void* x, unsigned long long seed, float p, long n, int dtype, hipStream_t stream) {
+  if (p < 0.f || p >= 1.f) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, L1D(dropout_kernel<T>, (n + 3) / 4, (T*)out, (const T*)x, (uint32_t)seed, (uint32_t)(seed >> 32), p, n))
+}
+int hdmoe_randn(float* out, unsigned long long seed, float scale, long n, hipStream_t stream) {
+  L1D(randn_kernel, (n + 3) / 4, out, (uint32_t)seed, (uint32_t)(seed >> 32), scale, n);
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// K6: normalisation kernels (fwd + bwd), NHWC / [rows][C]; statistics always in fp32.
+//   pixel-norm  : normalize(x, dim=[1])            reference models/model_internals.py:8-30, model_components.py:238
+//   GroupNorm   : nn.GroupNorm(G, C) (+ReLU / +mp_silu fused)   model_components.py:102-109, :491, :530
+//   LayerNorm   : nn.LayerNorm(C)                  model_components.py:495-496, :645
+#include "common.h"
+#include "hdmoe.h"
+
+namespace {
+
+constexpr int TPB = 256;
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+static inline unsigned grid_for(long n) {
+  long b = (n + TPB - 1) / TPB;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------- pixel norm (one thread per pixel row)
+template <typename T>
+__global__ void pixelnorm_fwd_kernel(T* xn, T* h, const T* x, int C, long rows) {
+  const float rc = rsqrtf((float)C);
+  GRID_STRIDE(r, rows) {
+    const T* p = x + r * C;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) { const float v = to_f(p[c]); ss += v * v; }
+    const float inv = 1.f / (1e-4f + sqrtf(ss) * rc);
+    for (int c = 0; c < C; ++c) {
+      const float v = to_f(p[c]) * inv;
+      xn[r * C + c] = from_f<T>(v);
+      if (h) h[r * C + c] = from_f<T>(mp_silu_f(v));
+    }
+  }
+}
+// g = dxn + dh * mp_silu'(xn);  dx = g/d - x * (sum g*x) * rc / (d^2 * n)
+template <typename T>
+__global__ void pixelnorm_bwd_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows) {
+  const float rc = rsqrtf((float)C);
+  GRID_STRIDE(r, rows) {
+    const T* p = x + r * C;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) { const float v = to_f(p[c]); ss += v * v; }
+    const float nrm = sqrtf(ss);
+    const float d = 1e-4f + nrm * rc, inv = 1.f / d;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = to_f(p[c]);
+      float g = dxn ? to_f(dxn[r * C + c]) : 0.f;
+      if (dh) g += to_f(dh[r * C + c]) * mp_silu_grad_f(v * inv);
+      dot += g * v;
+    }
+    const float k2 = nrm > 0.f ? dot * rc * inv * inv / nrm : 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = to_f(p[c]);
+      float g = dxn ? to_f(dxn[r * C + c]) : 0.f;
+      if (dh) g += to_f(dh[r * C + c]) * mp_silu_grad_f(v * inv);
+      dx[r * C + c] = from_f<T>(g * inv - k2 * v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+DEVI float act_f(float z, int act) { return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? mp_silu_f(z) : z); }
+DEVI float act_grad_f(float z, int act) { return act == 1 ? (z > 0.f ? 1.f : 0.f) : (act == 2 ? mp_silu_grad_f(z) : 1.f); }
+
+// per-group block reduction: thread t owns group t % G (requires blockDim % G == 0); result for group g in red[g]
+DEVI void group_reduce(float v, int G, float* part, float* red) {
+  __syncthreads();
+  part[threadIdx.x] = v;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float s = 0.f;
+    for (int t = threadIdx.x; t < (int)blockDim.x; t += G) s += part[t];
+    red[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// one block per sample; items = (position s, group g) pairs, item -> Cg contiguous channels; two-pass variance
+template <typename T>
+__global__ __launch_bounds__(512) void groupnorm_stats_kernel(float* mean, float* rstd, const T* x, long S, int C, int G, float eps) {
+  __shared__ float part[512];
+  __shared__ float red[64];
+  const int n = blockIdx.x, Cg = C / G;
+  const T* xs = x + (long)n * S * C;
+  const long items = S * G;
+  float acc = 0.f;
+  for (long it = threadIdx.x; it < items; it += blockDim.x) {
+    const T* p = xs + (it / G) * C + (it % G) * Cg;
+    for (int c = 0; c < Cg; ++c) acc += to_f(p[c]);
+  }
+  group_reduce(acc, G, part, red);
+  const float m = red[threadIdx.x % G] / (float)(S * Cg);
+  acc = 0.f;
+  for (long it = threadIdx.x; it < items; it += blockDim.x) {
+    const T* p = xs + (it / G) * C + (it % G) * Cg;
+    for (int c = 0; c < Cg; ++c) { const float d = to_f(p[c]) - m; acc += d * d; }
+  }
+  group_reduce(acc, G, part, red);
+  if ((int)threadIdx.x < G) {
+    mean[(long)n * G + threadIdx.x] = m;
+    rstd[(long)n * G + threadIdx.x] = rsqrtf(red[threadIdx.x] / (float)(S * Cg) + eps);
+  }
+}
+template <typename T>
+__global__ void groupnorm_apply_kernel(T* y, const T* x, const float* gamma, const float* beta, const float* mean,
+                                       const float* rstd, long S, int C, int G, int act, long n) {
+  const int Cg = C / G;
+  GRID_STRIDE(i, n) {
+    const long row = i / C; const int c = (int)(i - row * C);
+    const long sg = (row / S) * G + c / Cg;
+    const float z = (to_f(x[i]) - mean[sg]) * rstd[sg] * gamma[c] + beta[c];
+    y[i] = from_f<T>(act_f(z, act));
+  }
+}
+// bwd pass 1: per (sample, group) s1 = sum dz*gamma, s2 = sum dz*gamma*xhat ; per-channel dgamma/dbeta (atomics)
+template <typename T>
+__global__ __launch_bounds__(512) void groupnorm_bwd_stats_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const T* dy,
+                                                                 const T* x, const float* gamma, const float* beta,
+                                                                 const float* mean, const float* rstd, long S, int C, int G, int act) {
+  extern __shared__ float sm[];          // [2*C] per-channel partials
+  __shared__ float part[512];
+  __shared__ float red[64];
+  const int n = blockIdx.x, Cg = C / G;
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const long base = (long)n * S * C;
+  const long items = S * G;
+  const int g = threadIdx.x % G;
+  const float m = mean[(long)n * G + g], rs = rstd[(long)n * G + g];
+  float a1 = 0.f, a2 = 0.f;
+  for (long it = threadIdx.x; it < items; it += blockDim.x) {
+    const long off = base + (it / G) * C + g * Cg;
+    for (int c = 0; c < Cg; ++c) {
+      const int ch = g * Cg + c;
+      const float xh = (to_f(x[off + c]) - m) * rs;
+      const float dz = to_f(dy[off + c]) * act_grad_f(xh * gamma[ch] + beta[ch], act);
+      a1 += dz * gamma[ch];
+      a2 += dz * gamma[ch] * xh;
+      atomicAdd(&sm[ch], dz * xh);
+      atomicAdd(&sm[C + ch], dz);
+    }
+  }
+  group_reduce(a1, G, part, red);
+  if ((int)threadIdx.x < G) s1[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  group_reduce(a2, G, part, red);
+  if ((int)threadIdx.x < G) s2[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&dgamma[c], sm[c]);
+    atomicAdd(&dbeta[c], sm[C + c]);
+  }
+}
+template <typename T>
+__global__ void groupnorm_bwd_apply_kernel(T* dx, const T* dy, const T* x, const float* gamma, const float* beta, const float* mean,
+                                           const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long n) {
+  const int Cg = C / G;
+  const float invm = 1.f / (float)(S * Cg);
+  GRID_STRIDE(i, n) {
+    const long row = i / C; const int c = (int)(i - row * C);
+    const long sg = (row / S) * G + c / Cg;
+    const float rs = rstd[sg];
+    const float xh = (to_f(x[i]) - mean[sg]) * rs;
+    const float dz = to_f(dy[i]) * act_grad_f(xh * gamma[c] + beta[c], act);
+    dx[i] = from_f<T>(rs * (dz * gamma[c] - invm * (s1[sg] + xh * s2[sg])));
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm (one thread per row, C <= ~1024)
+template <typename T>
+__global__ void layernorm_fwd_kernel(T* y, float* mean, float* rstd, const T* x, const float* gamma, const float* beta, int C, float eps, long rows) {
+  GRID_STRIDE(r, rows) {
+    const T* p = x + r * C;
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) m += to_f(p[c]);
+    m /= (float)C;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = to_f(p[c]) - m; v += d * d; }
+    const float rs = rsqrtf(v / (float)C + eps);
+    mean[r] = m; rstd[r] = rs;
+    for (int c = 0; c < C; ++c) y[r * C + c] = from_f<T>((to_f(p[c]) - m) * rs * gamma[c] + beta[c]);
+  }
+}
+template <typename T>
+__global__ void layernorm_bwd_kernel(T* dx, float* dgamma, float* dbeta, const T* dy, const T* x, const float* gamma,
+                                     const float* mean, const float* rstd, int C, long rows) {
+  extern __shared__ float sm[];     // [2*C]
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  GRID_STRIDE(r, rows) {
+    const float m = mean[r], rs = rstd[r];
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float g = to_f(dy[r * C + c]), xh = (to_f(x[r * C + c]) - m) * rs;
+      a1 += g * gamma[c];
+      a2 += g * gamma[c] * xh;
+      atomicAdd(&sm[c], g * xh);
+      atomicAdd(&sm[C + c], g);
+    }
+    const float ic = 1.f / (float)C;
+    for (int c = 0; c < C; ++c) {
+      const float g = to_f(dy[r * C + c]), xh = (to_f(x[r * C + c]) - m) * rs;
+      dx[r * C + c] = from_f<T>(rs * (g * gamma[c] - ic * (a1 + xh * a2)));
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&dgamma[c], sm[c]);
+    atomicAdd(&dbeta[c], sm[C + c]);
+  }
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, CALL)                    \
+  if ((dtype) == HDMOE_F32) { using T = float; CALL; }   \
+  else if ((dtype) == HDMOE_BF16) { using T = bf16; CALL; } \
+  else return HDMOE_EDTYPE;
+
+extern "C" {
+
+int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_fwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)xn, (T*)h, (const T*)x, C, rows))
+  return hdmoe_launch_status();
+}
+int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, int dtype, hipStream_t stream) {
+  if (!dxn && !dh) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_bwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows))
+  return hdmoe_launch_status();
+}
+static int gn_check(int N, int C, int G) {
+  if (N < 1 || G < 1 || G > 64 || (G & (G - 1)) || C % G || C > 4096) return HDMOE_EINVAL;   // G must divide 512 (thread<->group map)
+  return HDMOE_OK;
+}
+int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int N,
+                        long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
+  if (gn_check(N, C, G)) return HDMOE_EINVAL;
+  const long n = (long)N * S * C;
+  DT_SWITCH(dtype, {
+    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, dim3(N), dim3(512), 0, stream, mean, rstd, (const T*)x, S, C, G, eps);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<T>, dim3(grid_for(n)), dim3(TPB), 0, stream, (T*)y, (const T*)x, gamma, beta, mean, rstd, S, C, G, act, n);
+  })
+  return hdmoe_launch_status();
+}
+// ws: 2*N*G floats of scratch; dgamma/dbeta accumulate (caller zeroes)
+int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
+                        int dtype, hipStream_t stream) {
+  if (gn_check(N, C, G)) return HDMOE_EINVAL;
+  const long n = (long)N * S * C;
+  float* s1 = ws; float* s2 = ws + (long)N * G;
+  DT_SWITCH(dtype, {
+    hipLaunchKernelGGL(groupnorm_bwd_stats_kernel<T>, dim3(N), dim3(512), 2 * C * sizeof(float), stream, s1, s2, dgamma, dbeta,
+                       (const T*)dy, (const T*)x, gamma, beta, mean, rstd, S, C, G, act);
+    hipLaunchKernelGGL(groupnorm_bwd_apply_kernel<T>, dim3(grid_for(n)), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
+                       gamma, beta, mean, rstd, s1, s2, S, C, G, act, n);
+  })
+  return hdmoe_launch_status();
+}
+int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
+                        int C, float eps, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)y, mean, rstd, (const T*)x, gamma, beta, C, eps, rows))
+  return hdmoe_launch_status();
+}
+int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, const void* x, const float* gamma,
+                        const float* mean, const float* rstd, long rows, int C, int dtype, hipStream_t stream) {
+  if (C > 4096) return HDMOE_EINVAL;
+  unsigned g = grid_for(rows);
+  if (g > 256) g = 256;
+  DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(g), dim3(TPB), 2 * C * sizeof(float), stream, (T*)dx, dgamma, dbeta,
+                                      (const T*)dy, (const T*)x, gamma, mean, rstd, C, rows))
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

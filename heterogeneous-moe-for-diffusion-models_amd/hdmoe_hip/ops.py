@@ -1,0 +1,1129 @@
+"""Autograd-aware wrappers over the HIP kernels (one torch.autograd.Function per fused op).
+
+Layout contract of this module: activation tensors are contiguous channel-last -- spatial ``(N, H, W, C)``,
+token ``(N, S, C)`` or matrix ``(M, C)`` -- in float32 or bfloat16.  "Vector path" tensors (per-sample scalars,
+``(B, F)`` embeddings, parameters and their gradients) are float32.  PyTorch is used for memory (``torch.empty`` /
+``zeros``), views and autograd bookkeeping only; every arithmetic op below is a call into libhdmoe_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from ._lib import call, dtype_code
+
+Tensor = torch.Tensor
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _dt(t: Tensor) -> int:
+    return dtype_code(t.dtype)
+
+
+def _f32(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("expected a float32 vector-path tensor")
+    return _c(t)
+
+
+_seed_state = {"seed": 0x5DEECE66D, "ctr": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the device counter RNG used for dropout masks and router logit noise."""
+    _seed_state["seed"] = int(seed) & 0xFFFFFFFFFFFF
+    _seed_state["ctr"] = 0
+
+
+def _next_seed() -> int:
+    _seed_state["ctr"] += 1
+    return ((_seed_state["seed"] * 0x9E3779B97F4A7C15) ^ (_seed_state["ctr"] * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+
+
+# =====================================================================================================
+# MP_Conv: weight prep + implicit GEMM conv (+dgrad, wgrad)
+# =====================================================================================================
+def _kernel_hw(w: Tensor):
+    if w.ndim == 4:
+        return int(w.shape[2]), int(w.shape[3])
+    if w.ndim == 2:
+        return 1, 1
+    raise ValueError(f"weight must be 2-D or 4-D, got {tuple(w.shape)}")
+
+
+class _MPConvFn(torch.autograd.Function):
+    """y = alpha * conv(x, prep(w)) + beta * res.   x: (N, H, W, Cphys).
+    ``tensors`` = G weights followed by 0 or G learnable gain scalars (one per group)."""
+
+    @staticmethod
+    def forward(ctx, x, res, seg, meta, *tensors):
+        (G, gain_val, alpha, beta, ones, training, normalize) = meta
+        weights, gains = tensors[:G], list(tensors[G:]) or None
+        x = _c(x)
+        N, H, W, Cphys = x.shape
+        O, I = int(weights[0].shape[0]), int(weights[0].shape[1])
+        khs = [_kernel_hw(w)[0] for w in weights]
+        kws = [_kernel_hw(w)[1] for w in weights]
+        # reference pads by the LAST kernel dim on both axes (model_internals.py:264-270)
+        pts = [(kw - 1) // 2 for kw in kws]
+        Hos = {H + (kw - 1) - kh + 1 for kh, kw in zip(khs, kws)}
+        if len(Hos) != 1:
+            raise ValueError("grouped conv: all groups must produce the same output size")
+        if any(w.shape[0] != O or w.shape[1] != I for w in weights):
+            raise ValueError("grouped conv: all groups must share (out_channels, in_channels)")
+        if I != Cphys + (1 if ones else 0):
+            raise RuntimeError(f"MP_Conv: input has {Cphys} channels, weight expects {I}")
+        Ho, Wo = Hos.pop(), W
+        Ipad = (I + 15) // 16 * 16
+        wstride = max(a * b for a, b in zip(khs, kws)) * O * Ipad
+        wf = torch.empty(G * wstride, dtype=x.dtype, device=x.device)
+        call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, 16, wf, wstride, None, 0,
+             1 if normalize else 0, 1 if training else 0, 0, _dt(x))
+        y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
+        call("hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta, seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1,
+             1 if ones else 0, khs, kws, pts, pts, _dt(x))
+        ctx.save_for_backward(x, seg, *tensors)
+        ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, seg, *tensors = ctx.saved_tensors
+        G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, has_res = ctx.meta
+        weights, gains = tensors[:G], list(tensors[G:]) or None
+        dy = _c(dy)
+        N, H, W, Cphys = x.shape
+        O, I = int(weights[0].shape[0]), int(weights[0].shape[1])
+        dt = x.dtype
+        dx = dres = None
+        nig = ctx.needs_input_grad
+        need_gain = gains is not None and any(nig[4 + G + g] for g in range(G))
+        need_w = any(nig[4 + g] for g in range(G)) or need_gain
+        if nig[0]:
+            Ipad = (I + 15) // 16 * 16
+            Opad = (O + 15) // 16 * 16
+            taps = max(a * b for a, b in zip(khs, kws))
+            wstride, wdstride = taps * O * Ipad, taps * I * Opad
+            wf = torch.empty(G * wstride, dtype=dt, device=x.device)
+            wd = torch.empty(G * wdstride, dtype=dt, device=x.device)
+            call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
+                 1 if normalize else 0, 0, 1, _dt(x))
+            dx = torch.empty_like(x)
+            pt_d = [kh - 1 - p for kh, p in zip(khs, pts)]
+            pl_d = [kw - 1 - p for kw, p in zip(kws, pts)]
+            # dgrad: conv over dy (O channels) with the flipped kernel; logical out channels I, stored Cphys
+            call("hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0, seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0,
+                 khs, kws, pt_d, pl_d, _dt(x))
+        if has_res and nig[1]:
+            dres = torch.empty_like(dy)
+            call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
+        dws: List[Optional[Tensor]] = [None] * G
+        dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
+        if need_w:
+            Gs = [torch.zeros((khs[g] * kws[g], O, I), dtype=torch.float32, device=x.device) for g in range(G)]
+            call("hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts,
+                 _dt(x))
+            dws = [torch.empty_like(w) for w in weights]
+            if need_gain:
+                dgs = [torch.zeros((), dtype=torch.float32, device=x.device) for _ in range(G)]
+            call("hdmoe_wprep_bwd", list(weights), gains, gain_val, Gs, dws, dgs if need_gain else None, khs, kws, G, O, I,
+                 1 if normalize else 0)
+            if alpha != 1.0:
+                for d in list(dws) + [d for d in dgs if d is not None]:
+                    call("hdmoe_axpby", d, d, None, alpha, 0.0, d.numel(), 0)
+        return (dx, dres, None, None, *dws, *dgs)
+
+
+def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: Optional[Tensor] = None, alpha: float = 1.0,
+            beta: float = 0.0, ones: bool = False, training: bool = False, normalize: bool = True) -> Tensor:
+    """Magnitude-preserving conv / linear (reference MP_Conv.forward, model_internals.py:253-275).
+
+    ``x``: (N,H,W,C) -> (N,Ho,Wo,O);  (N,S,C) -> (N,S,O);  (M,C) -> (M,O).  ``weights``: a tensor, or a list of
+    per-expert tensors together with ``seg`` (device int32 row offsets) for a grouped launch.
+    ``gain``: python float, a 0-dim float32 tensor (learnable out_gain), or a list of such tensors (one per group)."""
+    ws = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+    G = len(ws)
+    if isinstance(gain, (list, tuple)):
+        gts, gain_val = list(gain), 1.0
+    elif torch.is_tensor(gain):
+        gts, gain_val = [gain] * G, 1.0
+    else:
+        gts, gain_val = [], float(gain)
+    shape = x.shape
+    grouped = seg is not None
+    if x.ndim == 2:
+        x4 = x.reshape(shape[0], 1, 1, shape[1]) if grouped else x.reshape(1, 1, shape[0], shape[1])
+    elif x.ndim == 3:
+        x4 = x.reshape(shape[0], 1, shape[1], shape[2])
+    elif x.ndim == 4:
+        x4 = x
+    else:
+        raise ValueError("mp_conv: x must be 2-, 3- or 4-D")
+    if res is not None and x.ndim != 4:
+        res = res.reshape(x4.shape[0], x4.shape[1], x4.shape[2], -1)
+    meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize))
+    y = _MPConvFn.apply(x4, res, seg, meta, *ws, *gts)
+    if x.ndim == 2:
+        return y.reshape(shape[0], -1)
+    if x.ndim == 3:
+        return y.reshape(shape[0], shape[1], -1)
+    return y
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """Vit_expert.patch: nn.Conv2d(C, E, p, stride=p) with bias on the zero-padded image (model_components.py:670-679)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        N, H, W, C = x.shape
+        E, p = int(w.shape[0]), int(w.shape[2])
+        hp, wp = -(-H // p), -(-W // p)
+        Ipad = (C + 15) // 16 * 16
+        wf = torch.empty(p * p * E * Ipad, dtype=x.dtype, device=x.device)
+        call("hdmoe_wprep_fwd", [w], None, 1.0, [p], [p], 1, E, C, Ipad, 16, wf, wf.numel(), None, 0, 0, 0, 0, _dt(x))
+        y0 = torch.empty((N, hp, wp, E), dtype=x.dtype, device=x.device)
+        call("hdmoe_conv_fwd", x, wf, y0, None, 1.0, 0.0, None, 1, wf.numel(), N, H, W, hp, wp, C, C, Ipad, E, E, p, 0, [p], [p],
+             [0], [0], _dt(x))
+        y = torch.empty_like(y0)
+        call("hdmoe_bias_add", y, y0, b, N * hp * wp, E, _dt(x))
+        ctx.save_for_backward(x, w)
+        return y.reshape(N, hp * wp, E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, H, W, C = x.shape
+        E, p = int(w.shape[0]), int(w.shape[2])
+        hp, wp = -(-H // p), -(-W // p)
+        dy = _c(dy).reshape(N, hp, wp, E)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            Ipad = (C + 15) // 16 * 16
+            Epad = (E + 15) // 16 * 16
+            wf = torch.empty(p * p * E * Ipad, dtype=x.dtype, device=x.device)
+            wd = torch.empty(p * p * C * Epad, dtype=x.dtype, device=x.device)     # [(tap, c)][Epad] == 1x1 weight, p*p*C outputs
+            call("hdmoe_wprep_fwd", [w], None, 1.0, [p], [p], 1, E, C, Ipad, Epad, wf, wf.numel(), wd, wd.numel(), 0, 0, 0, _dt(x))
+            tok = torch.empty((N, hp, wp, p * p * C), dtype=x.dtype, device=x.device)
+            call("hdmoe_conv_fwd", dy, wd, tok, None, 1.0, 0.0, None, 1, wd.numel(), N, hp, wp, hp, wp, E, E, Epad, p * p * C,
+                 p * p * C, 1, 0, [1], [1], [0], [0], _dt(x))
+            dx = torch.empty_like(x)
+            call("hdmoe_patch_relayout", dx, tok, N, H, W, C, p, hp, wp, 0, 1, _dt(x))
+        if ctx.needs_input_grad[1]:
+            Gs = [torch.zeros((p * p, E, C), dtype=torch.float32, device=x.device)]
+            call("hdmoe_conv_wgrad", x, dy, Gs, None, 1, N, H, W, hp, wp, C, C, E, p, 0, [p], [p], [0], [0], _dt(x))
+            dw = torch.empty_like(w)
+            call("hdmoe_wprep_bwd", [w], None, 1.0, Gs, [dw], None, [p], [p], 1, E, C, 0)
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros(E, dtype=torch.float32, device=x.device)
+            call("hdmoe_colsum", db, dy, N * hp * wp, E, _dt(x))
+        return dx, dw, db
+
+
+def patch_embed(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """(N,H,W,C) -> tokens (N, ceil(H/p)*ceil(W/p), E)."""
+    return _PatchEmbedFn.apply(x, w, b)
+
+
+# =====================================================================================================
+# pointwise
+# =====================================================================================================
+class _AxpbyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        x = _c(x); y = _c(y)
+        out = torch.empty_like(x)
+        call("hdmoe_axpby", out, x, y, a, b, x.numel(), _dt(x))
+        ctx.ab = (a, b, y is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, has_y = ctx.ab
+        g = _c(g)
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(g); call("hdmoe_axpby", dx, g, None, a, 0.0, g.numel(), _dt(g))
+        if has_y and ctx.needs_input_grad[1]:
+            dy = torch.empty_like(g); call("hdmoe_axpby", dy, g, None, b, 0.0, g.numel(), _dt(g))
+        return dx, dy, None, None
+
+
+def axpby(x: Tensor, y: Optional[Tensor], a: float, b: float = 0.0) -> Tensor:
+    return _AxpbyFn.apply(x, y, float(a), float(b))
+
+
+def mp_sum(a: Tensor, b: Tensor, t: float = 0.5) -> Tensor:
+    """lerp(a,b,t)/sqrt((1-t)^2+t^2) (model_internals.py:50-66)."""
+    n = math.sqrt((1.0 - t) ** 2 + t ** 2)
+    return axpby(a, b, (1.0 - t) / n, t / n)
+
+
+class _AffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, c):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("hdmoe_affine", out, x, a, c, x.numel(), _dt(x))
+        ctx.a = a
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        dx = torch.empty_like(g)
+        call("hdmoe_axpby", dx, g, None, ctx.a, 0.0, g.numel(), _dt(g))
+        return dx, None, None
+
+
+def affine(x: Tensor, a: float, c: float) -> Tensor:
+    return _AffineFn.apply(x, float(a), float(c))
+
+
+class _MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x = _c(x); y = _c(y)
+        out = torch.empty_like(x)
+        call("hdmoe_mul", out, x, y, x.numel(), _dt(x))
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = _c(g)
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(g); call("hdmoe_mul", dx, g, y, g.numel(), _dt(g))
+        if ctx.needs_input_grad[1]:
+            dy = torch.empty_like(g); call("hdmoe_mul", dy, g, x, g.numel(), _dt(g))
+        return dx, dy
+
+
+def mul(x: Tensor, y: Tensor) -> Tensor:
+    return _MulFn.apply(x, y)
+
+
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = _c(x)
+        ctx.src = x.dtype
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+        call("hdmoe_cast", out, x, x.numel(), _dt(x), dtype_code(dtype))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        dx = torch.empty(g.shape, dtype=ctx.src, device=g.device)
+        call("hdmoe_cast", dx, g, g.numel(), _dt(g), dtype_code(ctx.src))
+        return dx, None
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+
+
+class _MPSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("hdmoe_mp_silu_fwd", out, x, x.numel(), _dt(x))
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _c(g)
+        dx = torch.empty_like(x)
+        call("hdmoe_mp_silu_bwd", dx, g, x, x.numel(), _dt(x))
+        return dx
+
+
+def mp_silu(x: Tensor) -> Tensor:
+    return _MPSiluFn.apply(x)
+
+
+class _SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("hdmoe_sigmoid_fwd", out, x, a, x.numel(), _dt(x))
+        ctx.save_for_backward(out)
+        ctx.a = a
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _c(g)
+        dx = torch.empty_like(y)
+        call("hdmoe_sigmoid_bwd", dx, g, y, ctx.a, y.numel(), _dt(y))
+        return dx, None
+
+
+def sigmoid(x: Tensor, a: float = 1.0) -> Tensor:
+    """sigmoid(a * x)."""
+    return _SigmoidFn.apply(x, float(a))
+
+
+class _FilmSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, e):
+        u = _c(u); e = _f32(e)
+        N, C = u.shape[0], u.shape[-1]
+        HW = u.numel() // (N * C)
+        out = torch.empty_like(u)
+        call("hdmoe_film_silu_fwd", out, u, e, N, HW, C, _dt(u))
+        ctx.save_for_backward(u, e)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, e = ctx.saved_tensors
+        g = _c(g)
+        N, C = u.shape[0], u.shape[-1]
+        HW = u.numel() // (N * C)
+        du = torch.empty_like(u)
+        de = torch.zeros_like(e)
+        call("hdmoe_film_silu_bwd", du, de, g, u, e, N, HW, C, _dt(u))
+        return du, de
+
+
+def film_silu(u: Tensor, e: Tensor) -> Tensor:
+    """mp_silu(u * e[n, c]) with e a float32 (N, C) embedding (model_components.py:242-243)."""
+    return _FilmSiluFn.apply(u, e)
+
+
+class _ScaleRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x = _c(x); s = _f32(s).reshape(-1)
+        rows = x.shape[0]
+        L = x.numel() // rows
+        out = torch.empty_like(x)
+        call("hdmoe_scale_rows_fwd", out, x, s, rows, L, _dt(x))
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = _c(g)
+        rows = x.shape[0]
+        L = x.numel() // rows
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ds = torch.zeros_like(s) if ctx.needs_input_grad[1] else None
+        call("hdmoe_scale_rows_bwd", dx, ds, g, x, s, rows, L, _dt(x))
+        return dx, ds
+
+
+def scale_rows(x: Tensor, s: Tensor) -> Tensor:
+    """out[n] = s[n] * x[n] with s a float32 (N,) vector."""
+    return _ScaleRowsFn.apply(x, s)
+
+
+class _Cat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        a = _c(a); b = _c(b)
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // Ca
+        out = torch.empty((*a.shape[:-1], Ca + Cb), dtype=a.dtype, device=a.device)
+        call("hdmoe_cat2_fwd", out, a, b, wa, wb, Ca, Cb, rows, _dt(a))
+        ctx.meta = (wa, wb, a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        wa, wb, sa, sb = ctx.meta
+        g = _c(g)
+        da = torch.empty(sa, dtype=g.dtype, device=g.device)
+        db = torch.empty(sb, dtype=g.dtype, device=g.device)
+        call("hdmoe_cat2_bwd", da, db, g, wa, wb, sa[-1], sb[-1], da.numel() // sa[-1], _dt(g))
+        return da, db, None, None
+
+
+def mp_cat(a: Tensor, b: Tensor, t: float = 0.5) -> Tensor:
+    """Channel-last mp_cat (model_internals.py:69-92)."""
+    na, nb = a.shape[-1], b.shape[-1]
+    c = math.sqrt((na + nb) / ((1.0 - t) ** 2 + t ** 2))
+    return _Cat2Fn.apply(a, b, c * (1.0 - t) / math.sqrt(na), c * t / math.sqrt(nb))
+
+
+class _ResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _c(x)
+        N, H, W, C = x.shape
+        ctx.mode = mode
+        if mode == "down":
+            out = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+            call("hdmoe_pool2", out, x, N, H // 2, W // 2, C, 0.25, _dt(x))
+        else:
+            out = torch.empty((N, H * 2, W * 2, C), dtype=x.dtype, device=x.device)
+            call("hdmoe_upsample2", out, x, N, H * 2, W * 2, C, 1.0, _dt(x))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        N, H, W, C = g.shape
+        if ctx.mode == "down":
+            dx = torch.empty((N, H * 2, W * 2, C), dtype=g.dtype, device=g.device)
+            call("hdmoe_upsample2", dx, g, N, H * 2, W * 2, C, 0.25, _dt(g))
+        else:
+            dx = torch.empty((N, H // 2, W // 2, C), dtype=g.dtype, device=g.device)
+            call("hdmoe_pool2", dx, g, N, H // 2, W // 2, C, 1.0, _dt(g))
+        return dx, None
+
+
+def resample(x: Tensor, mode: str = "keep") -> Tensor:
+    """f=[1,1] resample (model_internals.py:95-127): 'down' = 2x2 mean, 'up' = nearest x2."""
+    if mode == "keep":
+        return x
+    if mode not in ("down", "up"):
+        raise ValueError(f"Invalid mode: {mode}")
+    if mode == "down" and (x.shape[1] % 2 or x.shape[2] % 2):
+        raise RuntimeError("resample('down') needs even spatial dims")
+    return _ResampleFn.apply(x, mode)
+
+
+class _SeqReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        N, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (N * C)
+        out = torch.zeros((N, C), dtype=torch.float32, device=x.device)
+        call("hdmoe_seq_reduce", out, x, N, S, C, scale, _dt(x))
+        ctx.meta = (x.shape, x.dtype, scale, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt, scale, S = ctx.meta
+        g = _f32(g)
+        dx = torch.empty(shape, dtype=dt, device=g.device)
+        call("hdmoe_seq_bcast_add", dx, None, g, shape[0], S, shape[-1], scale, dtype_code(dt))
+        return dx, None
+
+
+def seq_mean(x: Tensor) -> Tensor:
+    """Mean over all middle dims: (N, ..., C) -> float32 (N, C)  (AdaptiveAvgPool2d(1) / text.mean(1))."""
+    N, C = x.shape[0], x.shape[-1]
+    return _SeqReduceFn.apply(x, 1.0 / (x.numel() // (N * C)))
+
+
+class _SeqBcastAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        x = _c(x); t = _f32(t)
+        N, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (N * C)
+        out = torch.empty_like(x)
+        call("hdmoe_seq_bcast_add", out, x, t, N, S, C, 1.0, _dt(x))
+        ctx.meta = (N, S, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, S, C = ctx.meta
+        g = _c(g)
+        dt_ = None
+        if ctx.needs_input_grad[1]:
+            dt_ = torch.zeros((N, C), dtype=torch.float32, device=g.device)
+            call("hdmoe_seq_reduce", dt_, g, N, S, C, 1.0, _dt(g))
+        return g, dt_
+
+
+def seq_bcast_add(x: Tensor, t: Tensor) -> Tensor:
+    """x[n, s, :] + t[n, :] (the q/k/v time biases of MP_Attention, model_internals.py:368-372)."""
+    return _SeqBcastAddFn.apply(x, t)
+
+
+class _BiasAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        x = _c(x); bias = _f32(bias)
+        L = bias.numel()
+        out = torch.empty_like(x)
+        call("hdmoe_bias_add", out, x, bias, x.numel() // L, L, _dt(x))
+        ctx.bshape = bias.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        db = None
+        if ctx.needs_input_grad[1]:
+            L = 1
+            for d in ctx.bshape:
+                L *= d
+            db = torch.zeros(ctx.bshape, dtype=torch.float32, device=g.device)
+            call("hdmoe_colsum", db, g, g.numel() // L, L, _dt(g))
+        return g, db
+
+
+def bias_add(x: Tensor, bias: Tensor) -> Tensor:
+    """x viewed as (rows, bias.numel()) + bias (pos_emb add, model_components.py:680)."""
+    return _BiasAddFn.apply(x, bias)
+
+
+class _LerpParamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a = _c(a); b = _c(b)
+        out = torch.empty_like(a)
+        call("hdmoe_lerp_param_fwd", out, a, b, alpha, a.numel(), _dt(a))
+        ctx.save_for_backward(a, b, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, alpha = ctx.saved_tensors
+        g = _c(g)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        dal = torch.zeros_like(alpha)
+        call("hdmoe_lerp_param_bwd", da, db, dal, g, a, b, alpha, a.numel(), _dt(a))
+        return da, db, dal
+
+
+def lerp_param(a: Tensor, b: Tensor, alpha: Tensor) -> Tensor:
+    """a + alpha*(b - a) with a learnable float32 scalar (model_config2.py:291)."""
+    return _LerpParamFn.apply(a, b, alpha)
+
+
+class _GateMixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, U, A):
+        logits = _c(logits); U = _c(U); A = _c(A)
+        C = U.shape[-1]
+        rows = U.numel() // C
+        out = torch.empty_like(U)
+        gate = torch.empty((*U.shape[:-1], 2), dtype=torch.float32, device=U.device)
+        call("hdmoe_gate_mix_fwd", out, gate, logits, U, A, rows, C, _dt(U))
+        ctx.save_for_backward(gate, U, A)
+        return out, gate
+
+    @staticmethod
+    def backward(ctx, g, dgate):
+        gate, U, A = ctx.saved_tensors
+        g = _c(g)
+        dgate = None if dgate is None else _f32(dgate)
+        C = U.shape[-1]
+        rows = U.numel() // C
+        dU, dA = torch.empty_like(U), torch.empty_like(A)
+        dl = torch.empty((*U.shape[:-1], 2), dtype=U.dtype, device=U.device)
+        call("hdmoe_gate_mix_bwd", dU, dA, dl, g, dgate, gate, U, A, rows, C, _dt(U))
+        return dl, dU, dA
+
+
+def gate_mix(logits: Tensor, U: Tensor, A: Tensor):
+    """softmax gate over 2 channels + mix + mp_sum (model_config2.py:297-301).  Returns (out, gate fp32)."""
+    return _GateMixFn.apply(logits, U, A)
+
+
+class _SoftmaxRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _f32(x)
+        out = torch.empty_like(x)
+        call("hdmoe_softmax_rows_fwd", out, x, x.numel() // x.shape[-1], x.shape[-1], scale)
+        ctx.save_for_backward(out)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _f32(g)
+        dx = torch.empty_like(y)
+        call("hdmoe_softmax_rows_bwd", dx, g, y, y.numel() // y.shape[-1], y.shape[-1], ctx.scale)
+        return dx, None
+
+
+def softmax_rows(x: Tensor, scale: float = 1.0) -> Tensor:
+    return _SoftmaxRowsFn.apply(x, float(scale))
+
+
+class _AdaLNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cond):
+        x = _f32(x); cond = _f32(cond)
+        B, F = x.shape
+        out = torch.empty_like(x)
+        call("hdmoe_adaln_fwd", out, x, cond, B, F)
+        ctx.save_for_backward(x, cond)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cond = ctx.saved_tensors
+        g = _f32(g)
+        B, F = x.shape
+        dx, dcond = torch.empty_like(x), torch.empty_like(cond)
+        call("hdmoe_adaln_bwd", dx, dcond, g, x, cond, B, F)
+        return dx, dcond
+
+
+def adaln(x: Tensor, cond: Tensor) -> Tensor:
+    """x*(1+gamma)+beta with cond = [gamma | beta] (B, 2F) (model_components.py:148-151)."""
+    return _AdaLNFn.apply(x, cond)
+
+
+class _TakeColPosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, e):
+        w = _f32(w)
+        B, E = w.shape
+        out = torch.empty(B, dtype=torch.float32, device=w.device)
+        call("hdmoe_take_col_pos_fwd", out, w, B, E, e)
+        ctx.save_for_backward(w)
+        ctx.e = e
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        B, E = w.shape
+        dw = torch.zeros_like(w)
+        call("hdmoe_take_col_pos_bwd", dw, _f32(g), w, B, E, ctx.e)
+        return dw, None
+
+
+def take_col_pos(w: Tensor, e: int) -> Tensor:
+    """(B,) float32: w[:, e] where positive, else 0 (the `out_router[:, i] > 0` mask, model_config1.py:26,35)."""
+    return _TakeColPosFn.apply(w, int(e))
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("hdmoe_dropout", out, x, seed, p, x.numel(), _dt(x))
+        ctx.meta = (p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.meta
+        g = _c(g)
+        dx = torch.empty_like(g)
+        call("hdmoe_dropout", dx, g, seed, p, g.numel(), _dt(g))
+        return dx, None, None
+
+
+def dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    if not training or p == 0.0:
+        return x
+    return _DropoutFn.apply(x, float(p), _next_seed())
+
+
+def randn_like(x: Tensor, scale: float) -> Tensor:
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("hdmoe_randn", out, _next_seed(), float(scale), out.numel())
+    return out
+
+
+# =====================================================================================================
+# layout / boundary
+# =====================================================================================================
+class _ToNHWCFn(torch.autograd.Function):
+    """float32 NCHW (contiguous) -> NHWC in `dtype`, optionally scaled per sample."""
+
+    @staticmethod
+    def forward(ctx, x, s, dtype):
+        x = _c(x)
+        N, C, H, W = x.shape
+        out = torch.empty((N, H, W, C), dtype=dtype, device=x.device)
+        call("hdmoe_nchw_to_nhwc", out, x, s, N, C, H * W, dtype_code(dtype))
+        ctx.save_for_backward(s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        g = _c(g)
+        N, H, W, C = g.shape
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        call("hdmoe_nhwc_to_nchw", dx, g, s, None, None, N, C, H * W, _dt(g))
+        return dx, None, None
+
+
+class _FromNHWCFn(torch.autograd.Function):
+    """out_nchw(fp32) = sf[n]*F_nhwc + sx[n]*x_nchw   (EDM D_x, model_config2.py:449)."""
+
+    @staticmethod
+    def forward(ctx, F, sf, x, sx):
+        F = _c(F)
+        N, H, W, C = F.shape
+        x = None if x is None else _c(x)
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=F.device)
+        call("hdmoe_nhwc_to_nchw", out, F, sf, x, sx, N, C, H * W, _dt(F))
+        ctx.save_for_backward(sf, sx)
+        ctx.meta = (F.dtype, x is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sf, sx = ctx.saved_tensors
+        fdt, has_x = ctx.meta
+        g = _c(g)
+        N, C, H, W = g.shape
+        dF = torch.empty((N, H, W, C), dtype=fdt, device=g.device)
+        call("hdmoe_nchw_to_nhwc", dF, g, sf, N, C, H * W, dtype_code(fdt))
+        dx = None
+        if has_x and ctx.needs_input_grad[2]:
+            dx = torch.empty_like(g)
+            if sx is None:
+                call("hdmoe_axpby", dx, g, None, 1.0, 0.0, g.numel(), 0)
+            else:
+                call("hdmoe_scale_rows_fwd", dx, g, sx, N, C * H * W, 0)
+        return dF, None, dx, None
+
+
+def to_nhwc(x: Tensor, scale: Optional[Tensor] = None, dtype: Optional[torch.dtype] = None) -> Tensor:
+    """Module-boundary ingest: logical NCHW -> contiguous (N,H,W,C)."""
+    dtype = dtype or x.dtype
+    if scale is None and dtype == x.dtype and x.is_contiguous(memory_format=torch.channels_last):
+        return x.permute(0, 2, 3, 1)                      # already channel-last in memory: a view
+    if x.dtype != torch.float32:
+        # non-fp32 NCHW input at a module boundary: relayout only (no arithmetic)
+        y = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        return cast(y, dtype) if scale is None else scale_rows(cast(y, dtype), scale)
+    return _ToNHWCFn.apply(x, scale, dtype)
+
+
+def from_nhwc(y: Tensor) -> Tensor:
+    """(N,H,W,C) -> logical (N,C,H,W) (channels_last strides, zero-copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+def nhwc_to_nchw_f32(F: Tensor, sf: Optional[Tensor] = None, x: Optional[Tensor] = None, sx: Optional[Tensor] = None) -> Tensor:
+    return _FromNHWCFn.apply(F, sf, x, sx)
+
+
+class _PatchRelayoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, meta):
+        N, H, W, C, p, hp, wp, order = meta
+        tok = _c(tok)
+        out = torch.empty((N, H, W, C), dtype=tok.dtype, device=tok.device)
+        call("hdmoe_patch_relayout", out, tok, N, H, W, C, p, hp, wp, order, 1, _dt(tok))
+        ctx.meta = meta
+        ctx.tshape = tok.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, C, p, hp, wp, order = ctx.meta
+        g = _c(g)
+        # tokens cover the padded hp*p x wp*p canvas; positions outside H x W receive no gradient
+        dtok = torch.zeros(ctx.tshape, dtype=g.dtype, device=g.device) if (hp * p != H or wp * p != W) else \
+            torch.empty(ctx.tshape, dtype=g.dtype, device=g.device)
+        call("hdmoe_patch_relayout", dtok, g, N, H, W, C, p, hp, wp, order, 0, _dt(g))
+        return dtok, None
+
+
+def pixel_shuffle_tokens(tok: Tensor, H: int, W: int, C: int, p: int) -> Tensor:
+    """tokens (N, hp*wp, C*p*p) in PixelShuffle feature order -> image (N,H,W,C), cropped (model_components.py:698-704)."""
+    N = tok.shape[0]
+    hp, wp = -(-H // p), -(-W // p)
+    return _PatchRelayoutFn.apply(tok, (N, H, W, C, p, hp, wp, 1))
+
+
+# =====================================================================================================
+# norms
+# =====================================================================================================
+class _PixelNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, with_silu):
+        x = _c(x)
+        C = x.shape[-1]
+        xn = torch.empty_like(x)
+        h = torch.empty_like(x) if with_silu else None
+        call("hdmoe_pixelnorm_fwd", xn, h, x, x.numel() // C, C, _dt(x))
+        ctx.save_for_backward(x)
+        ctx.with_silu = with_silu
+        if with_silu:
+            return xn, h
+        return xn
+
+    @staticmethod
+    def backward(ctx, dxn, dh=None):
+        (x,) = ctx.saved_tensors
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        call("hdmoe_pixelnorm_bwd", dx, _c(dxn), _c(dh), x, x.numel() // C, C, _dt(x))
+        return dx, None
+
+
+def pixel_norm(x: Tensor) -> Tensor:
+    """normalize(x, dim=[channel]) (model_internals.py:8-30)."""
+    return _PixelNormFn.apply(x, False)
+
+
+def pixel_norm_silu(x: Tensor):
+    """Returns (normalize(x, channel), mp_silu(of that)) in one pass (model_components.py:238-240)."""
+    return _PixelNormFn.apply(x, True)
+
+
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, act, eps):
+        x = _c(x)
+        N, C = x.shape[0], x.shape[-1]
+        S = x.numel() // (N * C)
+        mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        call("hdmoe_groupnorm_fwd", y, mean, rstd, x, gamma, beta, N, S, C, G, act, eps, _dt(x))
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.meta = (N, S, C, G, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, S, C, G, act = ctx.meta
+        g = _c(g)
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(beta)
+        ws = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
+        call("hdmoe_groupnorm_bwd", dx, dgamma, dbeta, ws, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
+        return dx, dgamma, dbeta, None, None, None
+
+
+ACT_NONE, ACT_RELU, ACT_MP_SILU = 0, 1, 2
+
+
+def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, act: int = ACT_NONE, eps: float = 1e-5) -> Tensor:
+    """nn.GroupNorm over a channel-last tensor (N, ..., C), optionally fused with ReLU / mp_silu."""
+    return _GroupNormFn.apply(x, gamma, beta, int(groups), int(act), float(eps))
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        call("hdmoe_layernorm_fwd", y, mean, rstd, x, gamma, beta, rows, C, eps, _dt(x))
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        g = _c(g)
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(gamma)
+        call("hdmoe_layernorm_bwd", dx, dgamma, dbeta, g, x, gamma, mean, rstd, x.numel() // C, C, _dt(x))
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
+    return _LayerNormFn.apply(x, gamma, beta, float(eps))
+
+
+# =====================================================================================================
+# attention core
+# =====================================================================================================
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, bias, H):
+        q = _c(q); k = _c(k); v = _c(v)
+        B, Sq, E = q.shape
+        Skv = k.shape[1]
+        D = E // H
+        Sb = 0
+        if bias is not None:
+            bias = _f32(bias)
+            Sb = bias.shape[-1]
+        out = torch.empty_like(q)
+        lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+        call("hdmoe_attn_fwd", out, lse, q, k, v, bias, B, Sq, Skv, H, D, Sb, _dt(q))
+        ctx.save_for_backward(q, k, v, bias, out, lse)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, bias, out, lse = ctx.saved_tensors
+        H = ctx.H
+        g = _c(g)
+        B, Sq, E = q.shape
+        Skv = k.shape[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        dbias = None
+        Sb = 0
+        if bias is not None:
+            Sb = bias.shape[-1]
+            if ctx.needs_input_grad[3]:
+                dbias = torch.zeros_like(bias)
+        call("hdmoe_attn_bwd", dq, dk, dv, dbias, delta, g, out, q, k, v, lse, bias, B, Sq, Skv, H, E // H, Sb, _dt(q))
+        return dq, dk, dv, dbias, None
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor], num_heads: int) -> Tensor:
+    """softmax(q k^T / sqrt(D) + bias) v per head; (B,S,E) tensors, head h = channels [h*D,(h+1)*D)."""
+    return _AttnFn.apply(q, k, v, bias, int(num_heads))
+
+
+# =====================================================================================================
+# router head + dispatch
+# =====================================================================================================
+class _RouterHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, noise, mask, k):
+        logits = _f32(logits)
+        B, E = logits.shape
+        noise = None if noise is None else _f32(noise)
+        mask = None if mask is None else _c(mask.to(torch.float32))
+        sparse = torch.empty_like(logits)
+        probs = torch.empty_like(logits)
+        xout = torch.empty_like(logits)
+        idx = torch.empty((B, k), dtype=torch.int32, device=logits.device)
+        call("hdmoe_router_head_fwd", sparse, probs, xout, idx, logits, noise, mask, B, E, k)
+        ctx.save_for_backward(sparse, probs, idx, mask)
+        ctx.k = k
+        ctx.mark_non_differentiable(idx)
+        return sparse, probs, xout, idx
+
+    @staticmethod
+    def backward(ctx, dsparse, dprobs, dxout, _didx):
+        sparse, probs, idx, mask = ctx.saved_tensors
+        B, E = sparse.shape
+        dl = torch.empty_like(sparse)
+        call("hdmoe_router_head_bwd", dl, _c(dsparse), _c(dprobs), _c(dxout), sparse, probs, idx, mask, B, E, ctx.k)
+        return dl, None, None, None
+
+
+def router_head(logits: Tensor, noise: Optional[Tensor], mask: Optional[Tensor], k: int):
+    """masked_fill -> softmax -> top-k -> softmax(top-k) -> sparse scatter (model_components.py:158-168).
+    Returns (sparse_weights, gate_probs, masked_logits, topk_idx int32)."""
+    return _RouterHeadFn.apply(logits, noise, mask, int(k))
+
+
+class DispatchPlan:
+    """Device-side expert-contiguous permutation of the routed (sample, expert) pairs."""
+
+    def __init__(self, sparse: Tensor, kcap: int):
+        sparse = _f32(sparse.detach())
+        B, E = sparse.shape
+        self.B, self.E, self.kcap = B, E, int(kcap)
+        self.R = B * self.kcap
+        dev = sparse.device
+        self.perm = torch.empty(self.R, dtype=torch.int32, device=dev)
+        self.row_expert = torch.empty(self.R, dtype=torch.int32, device=dev)
+        self.row_w = torch.empty(self.R, dtype=torch.float32, device=dev)
+        self.inv = torch.empty(self.R, dtype=torch.int32, device=dev)
+        self.seg = torch.empty(E + 1, dtype=torch.int32, device=dev)
+        call("hdmoe_dispatch_plan", self.perm, self.row_expert, self.row_w, self.inv, self.seg, sparse, B, E, self.kcap)
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        x = _c(x)
+        L = x.numel() // x.shape[0]
+        out = torch.empty((plan.R, *x.shape[1:]), dtype=x.dtype, device=x.device)
+        call("hdmoe_gather_rows", out, x, plan.perm, plan.R, L, _dt(x))
+        ctx.plan = plan
+        ctx.xshape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = _c(g)
+        L = g.numel() // plan.R
+        dx = torch.empty(ctx.xshape, dtype=g.dtype, device=g.device)
+        call("hdmoe_combine_rows_fwd", dx, g, plan.inv, None, plan.B, plan.kcap, L, _dt(g))
+        return dx, None
+
+
+def gather_rows(x: Tensor, plan: DispatchPlan) -> Tensor:
+    """x[perm] : (B, ...) -> (R, ...) in expert-contiguous order (zeros in unused rows)."""
+    return _GatherFn.apply(x, plan)
+
+
+class _CombineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ys, sparse, plan):
+        ys = _c(ys)
+        L = ys.numel() // plan.R
+        out = torch.empty((plan.B, *ys.shape[1:]), dtype=ys.dtype, device=ys.device)
+        call("hdmoe_combine_rows_fwd", out, ys, plan.inv, plan.row_w, plan.B, plan.kcap, L, _dt(ys))
+        ctx.save_for_backward(ys)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ys,) = ctx.saved_tensors
+        plan = ctx.plan
+        g = _c(g)
+        L = ys.numel() // plan.R
+        dys = torch.empty_like(ys)
+        dsp = torch.zeros((plan.B, plan.E), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        call("hdmoe_combine_rows_bwd", dys, dsp, g, ys, plan.perm, plan.row_expert, plan.row_w, plan.R, plan.E, L, _dt(ys))
+        return dys, dsp, None
+
+
+def combine_rows(ys: Tensor, sparse: Tensor, plan: DispatchPlan) -> Tensor:
+    """out[b] = sum over the rows r routed from sample b of sparse[b, e(r)] * ys[r]  (output[mask] += out*w)."""
+    return _CombineFn.apply(ys, sparse, plan)
+
+
+# =====================================================================================================
+# small vector-path helpers (no autograd needed: inputs are data, not parameters)
+# =====================================================================================================
+def fourier(x: Tensor, freqs: Tensor, phases: Tensor) -> Tensor:
+    """MP_Fourier.forward (model_internals.py:158-175); x must be 1-D."""
+    if x.ndim != 1:
+        raise RuntimeError("MP_Fourier expects a 1-D input")
+    x = _f32(x.detach().to(torch.float32))
+    out = torch.empty((x.shape[0], freqs.shape[0]), dtype=torch.float32, device=x.device)
+    call("hdmoe_fourier", out, x, _f32(freqs), _f32(phases), x.shape[0], freqs.shape[0])
+    return out
+
+
+def edm_coeffs(sigma: Tensor, sigma_data: float, B: int) -> Tensor:
+    """(4, B) float32: c_skip, c_out, c_in, c_noise (model_config2.py:431-438)."""
+    s = _f32(sigma.detach().to(torch.float32).reshape(-1))
+    coef = torch.empty((4, B), dtype=torch.float32, device=s.device)
+    call("hdmoe_edm_coeffs", coef, s, s.numel(), float(sigma_data), B)
+    return coef
+
+
+def sigmoid_scaling(c_noise: Tensor, transition_point: float, softness: float):
+    """(s_vit (B,), s_unet (B,), scaling_factors (B,2)) (model_config2.py:244-249)."""
+    c = _f32(c_noise)
+    B = c.shape[0]
+    sv = torch.empty(B, dtype=torch.float32, device=c.device)
+    su = torch.empty_like(sv)
+    pair = torch.empty((B, 2), dtype=torch.float32, device=c.device)
+    call("hdmoe_sigmoid_scaling", sv, su, pair, c, float(transition_point), float(softness), B)
+    return sv, su, pair

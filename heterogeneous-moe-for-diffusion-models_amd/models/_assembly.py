@@ -1,0 +1,186 @@
+"""Shared implementation behind models/model_config1.py and models/model_config2.py (the reference keeps two
+near-identical 467-line files; here they are thin subclasses of the bases below).
+
+Dispatch (reference model_config1.py:11-39) is done without the reference's per-expert host syncs
+(``mask.any()`` + boolean indexing): a device-side plan permutes the routed samples into expert-contiguous rows,
+the U-Net bank runs as grouped launches over those rows, and a weighted combine un-permutes the result.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+import hdmoe_hip
+from hdmoe_hip import ops
+from models import model_components as m
+from models import model_internals as util
+
+Tensor = torch.Tensor
+
+
+def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_emb: Tensor, text2d: Optional[Tensor],
+                   kcap: Optional[int] = None) -> Tensor:
+    """x channel-last (B,H,W,C) -> (B,H,W,C)."""
+    mods = list(experts)
+    E = len(mods)
+    if all(isinstance(e, m.Unet_expert) for e in mods) and E <= 8:
+        plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
+        xs = ops.gather_rows(x, plan)
+        ts = ops.gather_rows(time_emb, plan)
+        tx = None if text2d is None else ops.gather_rows(text2d, plan)
+        ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg)
+        return ops.combine_rows(ys, out_router, plan)
+    # ViT experts have per-expert token counts (heterogeneous patch sizes) and are FLOP-trivial (<1 % of a step):
+    # evaluate each on the whole batch and keep only the routed samples (weight 0 elsewhere) -- still sync-free.
+    out = None
+    for i, expert in enumerate(mods):
+        w = ops.take_col_pos(out_router, i)                       # (B,): weight where routed, exact 0 elsewhere
+        if isinstance(expert, m.Vit_expert):
+            y = expert._fwd(x, time_emb, text2d)
+        else:
+            y = ops.to_nhwc(expert(x=ops.from_nhwc(x), time_emb=time_emb, text_emb=text2d))
+        y = ops.scale_rows(y, w)
+        out = y if out is None else ops.axpby(out, y, 1.0, 1.0)
+    return out
+
+
+def router_to_unet_experts(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_emb: Tensor,
+                           text_emb: Tensor) -> Tensor:
+    """Drop-in for the reference helper (model_config1.py:11-39): x logical NCHW, out_router (B,E) sparse weights."""
+    text2d = text_emb
+    if text_emb is not None:
+        text2d = ops.cast(text_emb, torch.float32)
+        if text2d.ndim == 3:
+            text2d = ops.seq_mean(text2d)
+    te = ops.cast(time_emb, torch.float32)
+    return ops.from_nhwc(_dispatch_nhwc(ops.to_nhwc(x), experts, out_router, te, text2d))
+
+
+class _HDMOEMBase(nn.Module):
+    """Stem -> two noisy-top-k routers -> U-Net bank + ViT bank -> cross-attention fusion -> text cross-attention
+    -> soft gate -> head (reference model_config2.py:42-303 / model_config1.py:42-309)."""
+
+    _has_scaling_net = False
+
+    def __init__(self, IN_in_channels: int, IN_img_resolution: int, internal_channels: int, time_emb_dim: int,
+                 text_emb_dim: int, num_experts: int, top_k: int, Fourier_bandwidth: float, VIT_num_blocks: int,
+                 VIT_patch_sizes: List[int], VIT_num_groups: int, VIT_num_heads: int, VIT_emb_size: int, Unet_num_blocks: int,
+                 Unet_channel_mult: list, Unet_kernel_sizes: List[Tuple[int, int]], Unet_model_channels: Optional[int] = 192,
+                 Unet_channel_mult_emb: Optional[int] = None, Unet_label_balance: Optional[float] = 0.5,
+                 Unet_concat_balance: Optional[float] = 0.5):
+        super().__init__()
+        self.internal_channels = internal_channels
+        self.top_k = top_k
+        self.input_proj = util.MP_Conv(in_channels=IN_in_channels, out_channels=self.internal_channels, kernel=(3, 3))
+        self.Fourier_emb = util.MP_Fourier(num_channels=time_emb_dim // 2, bandwidth=Fourier_bandwidth)
+        self.out_fourier1 = util.MP_Conv(in_channels=time_emb_dim // 2, out_channels=time_emb_dim * 2, kernel=())
+        self.out_fourier2 = util.MP_Conv(in_channels=time_emb_dim * 2, out_channels=time_emb_dim, kernel=())
+        if self._has_scaling_net:                                            # registration order as in the reference
+            self.scaling_net = m.Scaling_router(emb_dim=time_emb_dim, num_experts=2)
+        self.Unet_router = m.Router(in_channels=self.internal_channels, time_dim=time_emb_dim, top_k=top_k, num_experts=num_experts)
+        self.vit_router = m.Router(in_channels=self.internal_channels, time_dim=time_emb_dim, top_k=top_k, num_experts=num_experts)
+        self.alpha_txt = nn.Parameter(torch.tensor(0.0))
+        self.Unet_experts = nn.ModuleList()
+        for i in range(num_experts):
+            self.Unet_experts.append(m.Unet_expert(img_resolution=IN_img_resolution, img_channels=self.internal_channels,
+                                                   time_emb_dim=time_emb_dim, text_emb_dim=text_emb_dim,
+                                                   num_blocks=Unet_num_blocks, channel_mult=Unet_channel_mult,
+                                                   kernel_size=Unet_kernel_sizes[i], label_balance=Unet_label_balance,
+                                                   concat_balance=Unet_concat_balance, model_channels=Unet_model_channels,
+                                                   channel_mult_emb=Unet_channel_mult_emb))
+        self.VIT_experts = nn.ModuleList()
+        for i in range(num_experts):
+            self.VIT_experts.append(m.Vit_expert(num_heads=VIT_num_heads, num_groups=VIT_num_groups, in_channels=self.internal_channels,
+                                                 seq_ln=math.ceil(IN_img_resolution / VIT_patch_sizes[i]) ** 2,
+                                                 emb_dim=VIT_emb_size, num_blocks=VIT_num_blocks, patch_size=VIT_patch_sizes[i],
+                                                 text_dim=text_emb_dim, time_dim=time_emb_dim))
+        self.cross_attn = util.MP_Attention(num_heads=VIT_num_heads, emb_dim=self.internal_channels, seq_ln=IN_img_resolution ** 2,
+                                            context_dim=self.internal_channels, attn_balance=0.5, is_cross_attn=True)
+        self.cross_attn_text = util.MP_Attention(num_heads=VIT_num_heads, emb_dim=self.internal_channels,
+                                                 seq_ln=IN_img_resolution ** 2, context_dim=text_emb_dim, attn_balance=0.5,
+                                                 is_cross_attn=True)
+        self.gate1 = util.MP_Conv(in_channels=self.internal_channels * 2, out_channels=self.internal_channels, kernel=(1, 1))
+        self.gate2 = util.MP_Conv(in_channels=self.internal_channels, out_channels=2, kernel=(1, 1))
+        self.output_proj = util.MP_Conv(in_channels=self.internal_channels, out_channels=IN_in_channels, kernel=(3, 3))
+
+    # -- path scaling: the only place the two variants differ before the fusion ------------------------------------------
+    def _scaling(self, time_vec: Tensor, time_embed: Tensor, zeta, **kw):
+        raise NotImplementedError
+
+    def _fusion_inputs(self, fu: Tensor, fv: Tensor, s_vit: Tensor, s_unet: Tensor, **kw):
+        raise NotImplementedError
+
+    def _fwd(self, x: Tensor, time_vec: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor, zeta, **kw):
+        """x: channel-last fp32 (B,H,W,C_in).  Returns the 7-tuple with `out` and `out_gate` still channel-last."""
+        B, H, W, _ = x.shape
+        cdt = hdmoe_hip.compute_dtype()
+        time_vec = ops.cast(time_vec, torch.float32)
+        te = self.Fourier_emb(time_vec)
+        te = self.out_fourier1._fwd(te)
+        te = self.out_fourier2._fwd(ops.mp_silu(te))
+        feats = self.input_proj._fwd(x)                                     # stem stays fp32 (feeds both router trunks)
+        s_vit, s_unet, scaling = self._scaling(time_vec, te, zeta, **kw)
+        in_unet = ops.scale_rows(feats, s_unet)
+        in_vit = ops.scale_rows(feats, s_vit)
+        w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
+        w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
+        text2d = None
+        text_c = None
+        if text_emb is not None:
+            text32 = ops.cast(text_emb, torch.float32)
+            text2d = ops.seq_mean(text32) if text32.ndim == 3 else text32
+            text_c = ops.cast(text32, cdt)
+        out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
+        out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
+        C = self.internal_channels
+        fu = out_u.reshape(B, H * W, C)                                     # channel-last image == (B, S, C) tokens
+        fv = out_v.reshape(B, H * W, C)
+        q, ctx = self._fusion_inputs(fu, fv, s_vit, s_unet, **kw)
+        a = self.cross_attn(query=q, context=ctx, gain_s=1.0, gain_t=1.0)
+        at = self.cross_attn_text(query=a, context=text_c, gain_s=1.0, gain_t=1.0)
+        a = ops.lerp_param(a, at, self.alpha_txt)                           # a + alpha_txt * (at - a)
+        a_img = a.reshape(B, H, W, C)
+        g = self.gate1._fwd(ops.mp_cat(out_u, a_img, 0.5))
+        g = self.gate2._fwd(ops.mp_silu(g))
+        mixed, gate = ops.gate_mix(g, out_u, a_img)                         # softmax gate + mix + mp_sum(out_u, ., 0.5)
+        out = self.output_proj._fwd(mixed)
+        return out, p_unet, raw_unet, p_vit, raw_vit, scaling, gate
+
+    def _public(self, res):
+        out, p_u, raw_u, p_v, raw_v, scaling, gate = res
+        return ops.nhwc_to_nchw_f32(out), p_u, raw_u, p_v, raw_v, scaling, ops.from_nhwc(gate)
+
+
+class _PrecondBase(nn.Module):
+    """EDM preconditioning wrapper (reference model_config2.py:306-468)."""
+
+    _net_cls = None
+
+    def __init__(self, sigma_data: Optional[float] = 0.5, log_var_channels: Optional[int] = 128, **net_kwargs):
+        super().__init__()
+        self.sigma_data = sigma_data
+        self.log_var_channels = log_var_channels
+        self.num_experts = net_kwargs["num_experts"]
+        self.log_var_fourier = util.MP_Fourier(num_channels=self.log_var_channels)
+        self.log_var_linear = util.MP_Conv(in_channels=self.log_var_channels, out_channels=1, kernel=())
+        self.net = self._net_cls(**net_kwargs)
+
+    def _forward(self, x: Tensor, sigma: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor, zeta,
+                 return_log_var: bool, **kw):
+        B = x.shape[0]
+        coef = ops.edm_coeffs(sigma, self.sigma_data, B)                    # rows: c_skip, c_out, c_in, c_noise
+        c_skip, c_out, c_in, c_noise = coef[0], coef[1], coef[2], coef[3]
+        x32 = ops.cast(x, torch.float32)
+        xs = ops.to_nhwc(x32, scale=c_in, dtype=torch.float32)              # x * c_in, channel-last
+        out, p_u, raw_u, p_v, raw_v, scaling, gate = self.net._fwd(xs, c_noise, text_emb, Unet_router_mask, Vit_router_mask,
+                                                                    zeta, **kw)
+        # D_x = c_skip * (x * c_in) + c_out * F   (the reference uses the already-scaled x, :440/:449)
+        D_x = ops.nhwc_to_nchw_f32(out, c_out, x32, ops.mul(c_skip, c_in))
+        log_var = None
+        if return_log_var:
+            log_var = self.log_var_linear._fwd(self.log_var_fourier(c_noise)).reshape(-1, 1, 1, 1)
+        return {"denoised": D_x, "Unet_router_loss": p_u, "Unet_raw": raw_u, "vit_router_loss": p_v, "vit_raw": raw_v,
+                "scaling_net_out": scaling, "out_gate": ops.from_nhwc(gate), "log_var": log_var}

@@ -1,0 +1,352 @@
+"""Routers and experts -- drop-in for the reference's ``models/model_components.py``.
+
+Class names, constructor / forward signatures, attribute names and state_dict keys follow the reference
+(Scaling_router:7, Router:68, Unet_block:171, Unet_expert:255, Vit_block:435, Vit_expert:564).  Public ``forward``
+methods speak the reference's logical layouts (NCHW images, (B,S,C) tokens); ``_fwd`` methods and the
+``*_bank_forward`` functions work channel-last and can run a whole bank of heterogeneous experts in one grouped
+launch per layer (``seg`` = device-side row offsets from the dispatch plan).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+import models.model_internals as m
+from hdmoe_hip import ops
+
+Tensor = torch.Tensor
+
+
+class Scaling_router(nn.Module):
+    """2-way soft gate whose rows sum to 2 (reference model_components.py:7-66)."""
+
+    def __init__(self, emb_dim: Optional[int] = 3, num_experts: Optional[int] = 2, dropout: Optional[float] = 0.2):
+        super().__init__()
+        self.soft_route = nn.Sequential(
+            m.MP_Conv(in_channels=emb_dim, out_channels=emb_dim * 2, kernel=()),
+            nn.GroupNorm(1, emb_dim * 2),
+            nn.ReLU(),
+            m.MP_Conv(in_channels=emb_dim * 2, out_channels=emb_dim * 4, kernel=()),
+            nn.GroupNorm(1, emb_dim * 4),
+            nn.ReLU(),
+            nn.Dropout(dropout),
+        )
+        self.linear = m.MP_Conv(in_channels=emb_dim * 4, out_channels=num_experts, kernel=())
+
+    def forward(self, x: Tensor, zeta: Optional[float] = 1e-2) -> Tensor:
+        if x.ndim == 3:
+            x = x.squeeze(1)
+        sr = self.soft_route
+        x = ops.group_norm(sr[0]._fwd(x), sr[1].weight, sr[1].bias, 1, ops.ACT_RELU, sr[1].eps)
+        x = ops.group_norm(sr[3]._fwd(x), sr[4].weight, sr[4].bias, 1, ops.ACT_RELU, sr[4].eps)
+        x = ops.dropout(x, sr[6].p, self.training)
+        x = self.linear._fwd(x)
+        if self.training:
+            x = ops.axpby(x, ops.randn_like(x, zeta), 1.0, 1.0)
+        return ops.softmax_rows(x, 2.0)
+
+
+class Router(nn.Module):
+    """Sparse noisy top-k gate (reference model_components.py:68-168).
+    Returns (sparse_gate_weights, gate_probs, masked_logits), each (B, num_experts)."""
+
+    def __init__(self, in_channels: Optional[int] = 3, time_dim: Optional[int] = 256, top_k: Optional[int] = 1,
+                 num_experts: Optional[int] = 5, dropout: Optional[float] = 0.2):
+        super().__init__()
+        self.hard_route = nn.Sequential(
+            m.MP_Conv(in_channels=in_channels, out_channels=in_channels * 2, kernel=(3, 3)),
+            nn.GroupNorm(1, in_channels * 2),
+            nn.ReLU(),
+            m.MP_Conv(in_channels=in_channels * 2, out_channels=in_channels * 4, kernel=(3, 3)),
+            nn.GroupNorm(1, in_channels * 4),
+            nn.ReLU(),
+            m.MP_Conv(in_channels=in_channels * 4, out_channels=in_channels * 4, kernel=(3, 3)),
+            nn.GroupNorm(1, in_channels * 4),
+            nn.ReLU(),
+            nn.AdaptiveAvgPool2d((1, 1)),
+            nn.Dropout(dropout),
+        )
+        self.out_router = in_channels * 4
+        self.time_linear = m.MP_Conv(in_channels=time_dim, out_channels=self.out_router * 2, kernel=())
+        self.linear = m.MP_Conv(in_channels=in_channels * 4, out_channels=num_experts, kernel=())
+        self.k = top_k
+
+    def _fwd(self, x: Tensor, time_emb: Tensor, mask: Optional[Tensor], zeta):
+        """x channel-last (B,H,W,C); returns (sparse, probs, logits, topk_idx)."""
+        hr = self.hard_route
+        for ci, gi in ((0, 1), (3, 4), (6, 7)):
+            x = ops.group_norm(hr[ci]._fwd(x), hr[gi].weight, hr[gi].bias, 1, ops.ACT_RELU, hr[gi].eps)
+        x = ops.seq_mean(x)                                             # AdaptiveAvgPool2d(1) -> fp32 (B, 4C)
+        x = ops.dropout(x, hr[10].p, self.training)
+        if time_emb.ndim == 3:
+            time_emb = time_emb.squeeze(1)
+        cond = self.time_linear._fwd(ops.mp_silu(ops.cast(time_emb, torch.float32)))
+        x = ops.adaln(x, cond)
+        logits = self.linear._fwd(x)
+        noise = ops.randn_like(logits, zeta) if self.training else None
+        return ops.router_head(logits, noise, mask, self.k)
+
+    def forward(self, x: Tensor, time_emb: Tensor, mask: Optional[Tensor] = None, zeta: Optional[float] = 1e-2):
+        sparse, probs, logits, _ = self._fwd(ops.to_nhwc(x), time_emb, mask, zeta)
+        return sparse, probs, logits
+
+
+# ------------------------------------------------------------------------------------------------------------
+# U-Net expert(s).  Every function takes a LIST of structurally identical modules (one per expert, possibly with
+# different kernel sizes) and runs them as one grouped launch per layer.
+# ------------------------------------------------------------------------------------------------------------
+def _w(mods: Sequence[nn.Module], path: str) -> List[Tensor]:
+    out = []
+    for mod in mods:
+        for p in path.split("."):
+            mod = getattr(mod, p) if not p.isdigit() else mod[int(p)]
+        out.append(mod)
+    return out
+
+
+def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding: Tensor, seg: Optional[Tensor]) -> Tensor:
+    """Unet_block.forward (reference model_components.py:232-253) over a bank of same-shaped blocks."""
+    b0 = blocks[0]
+    tr = b0.training
+
+    def conv(name, inp, gain=1.0, **kw):
+        return ops.mp_conv(inp, [getattr(b, name).weights for b in blocks], gain, seg=seg, training=tr, **kw)
+
+    emb = ops.affine(conv("emb_layer", embedding, b0.emb_gain), 1.0, 1.0)           # 1 + emb_layer(e) * gain
+    x = ops.resample(x, b0.resample)
+    t = b0.residual_balance
+    n = ((1.0 - t) ** 2 + t ** 2) ** 0.5
+    if b0.type == "enc":
+        if b0.conv_skip is not None:
+            x = conv("conv_skip", x)
+        x, h = ops.pixel_norm_silu(x)
+    else:
+        h = ops.mp_silu(x)
+    y = conv("conv_res1", h, b0.conv_gain1)
+    y = ops.film_silu(y, emb)
+    y = ops.dropout(y, b0.dropout, tr and b0.dropout != 0)
+    if b0.type == "dec" and b0.conv_skip is not None:
+        x = conv("conv_skip", x)
+    # conv_res2 with mp_sum(x, main, residual_balance) fused into its epilogue
+    return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=(1.0 - t) / n)
+
+
+class Unet_block(nn.Module):
+    """EDM2-style residual block with a per-expert kernel size (reference model_components.py:171-253)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel: tuple, emb_size: int, resample: Optional[str] = "keep",
+                 Type: Optional[str] = "enc", residual_balance: Optional[float] = 0.5, Dropout: Optional[float] = 0.2,
+                 emb_gain: Optional[float] = 1.0, conv_gain: Optional[float] = 1.0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.emb_size = emb_size
+        self.residual_balance = residual_balance
+        self.type = Type
+        self.resample = resample
+        self.kernel = kernel
+        self.dropout = Dropout
+        self.emb_gain = emb_gain
+        self.conv_gain1 = conv_gain
+        self.conv_gain2 = conv_gain
+        self.conv_skip = m.MP_Conv(in_channels=in_channels, out_channels=out_channels, kernel=(1, 1)) \
+            if in_channels != out_channels else None
+        self.emb_layer = m.MP_Conv(in_channels=emb_size, out_channels=out_channels, kernel=())
+        self.conv_res1 = m.MP_Conv(in_channels=out_channels if self.type == "enc" else in_channels,
+                                   out_channels=out_channels, kernel=self.kernel)
+        self.conv_res2 = m.MP_Conv(in_channels=out_channels, out_channels=out_channels, kernel=self.kernel)
+
+    def forward(self, x: Tensor, embedding: Tensor) -> Tensor:
+        emb = ops.cast(embedding, torch.float32)
+        return ops.from_nhwc(unet_block_bank_forward([self], ops.to_nhwc(x), emb, None))
+
+
+def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_emb: Tensor, text_emb: Optional[Tensor],
+                             seg: Optional[Tensor]) -> Tensor:
+    """Unet_expert.forward (reference model_components.py:389-433) over a bank of experts.
+    x: (R,H,W,C) channel-last rows in expert-contiguous order; time_emb (R,T) / text_emb (R,text_dim) fp32."""
+    e0 = experts[0]
+    tr = e0.training
+
+    def conv(mods, inp, gain=1.0, **kw):
+        return ops.mp_conv(inp, [mm.weights for mm in mods], gain, seg=seg, training=tr, **kw)
+
+    emb = conv([e.map_noise for e in experts], time_emb)
+    if e0.map_text is not None and text_emb is not None:
+        if text_emb.ndim == 3:
+            text_emb = ops.seq_mean(text_emb)
+        emb = ops.mp_sum(emb, conv([e.map_text for e in experts], text_emb), e0.label_balance)
+    emb = ops.mp_silu(emb)
+    skips = []
+    for name in e0.encoders.keys():
+        mods = [e.encoders[name] for e in experts]
+        if "conv" in name:
+            x = conv(mods, x, ones=True)                         # torch.cat([x, ones]) folded into the conv (:416)
+        else:
+            x = unet_block_bank_forward(mods, x, emb, seg)
+        skips.append(x)
+    for name in e0.decoders.keys():
+        mods = [e.decoders[name] for e in experts]
+        if "block" in name:
+            x = ops.mp_cat(x, skips.pop(), e0.concat_balance)
+        x = unet_block_bank_forward(mods, x, emb, seg)
+    return conv([e.out_conv for e in experts], x, [e.out_gain for e in experts])
+
+
+class Unet_expert(nn.Module):
+    """Magnitude-preserving U-Net expert (reference model_components.py:255-433)."""
+
+    def __init__(self, img_resolution: int, img_channels: int, time_emb_dim: int, text_emb_dim: int, channel_mult: list,
+                 model_channels: Optional[int] = 192, channel_mult_emb: Optional[int] = None, num_blocks: Optional[int] = 3,
+                 kernel_size: Optional[tuple] = (3, 3), label_balance: Optional[float] = 0.5,
+                 concat_balance: Optional[float] = 0.5):
+        super().__init__()
+        self.block_channels = [model_channels * i for i in channel_mult]
+        self.emb_size = model_channels * channel_mult_emb if channel_mult_emb is not None else max(self.block_channels)
+        self.label_balance = label_balance
+        self.concat_balance = concat_balance
+        self.out_gain = nn.Parameter(torch.zeros([]))
+        self.map_noise = m.MP_Conv(in_channels=time_emb_dim, out_channels=self.emb_size, kernel=())
+        self.map_text = m.MP_Conv(in_channels=text_emb_dim, out_channels=self.emb_size, kernel=()) if text_emb_dim > 0 else None
+        self.encoders = nn.ModuleDict()
+        self.out_channels = img_channels + 1
+        for level, channel in enumerate(self.block_channels):
+            res = img_resolution >> level
+            if level == 0:
+                cin = self.out_channels
+                self.out_channels = channel
+                self.encoders[f"{res}x{res}_conv"] = m.MP_Conv(in_channels=cin, out_channels=self.out_channels, kernel=kernel_size)
+            else:
+                self.encoders[f"{res}x{res}_down"] = Unet_block(in_channels=self.out_channels, out_channels=self.out_channels,
+                                                                kernel=kernel_size, Type="enc", resample="down",
+                                                                emb_size=self.emb_size)
+            for i in range(num_blocks):
+                cin = self.out_channels
+                self.out_channels = channel
+                self.encoders[f"{res}x{res}_block{i}"] = Unet_block(in_channels=cin, out_channels=self.out_channels,
+                                                                    emb_size=self.emb_size, Type="enc", resample="keep",
+                                                                    kernel=kernel_size)
+        self.decoders = nn.ModuleDict()
+        skips = [block.out_channels for _, block in self.encoders.items()]
+        for level, channel in reversed(list(enumerate(self.block_channels))):
+            res = img_resolution >> level
+            if level == len(self.block_channels) - 1:
+                for tag in ("in0", "in1"):
+                    self.decoders[f"{res}x{res}_{tag}"] = Unet_block(in_channels=self.out_channels, out_channels=self.out_channels,
+                                                                     emb_size=self.emb_size, Type="dec", resample="keep",
+                                                                     kernel=kernel_size)
+            else:
+                self.decoders[f"{res}x{res}_up"] = Unet_block(in_channels=self.out_channels, out_channels=self.out_channels,
+                                                              emb_size=self.emb_size, Type="dec", resample="up",
+                                                              kernel=kernel_size)
+            for i in range(num_blocks + 1):
+                cin = self.out_channels + skips.pop()
+                self.out_channels = channel
+                self.decoders[f"{res}x{res}_block{i}"] = Unet_block(in_channels=cin, out_channels=self.out_channels,
+                                                                    emb_size=self.emb_size, Type="dec", resample="keep",
+                                                                    kernel=kernel_size)
+        self.out_conv = m.MP_Conv(in_channels=self.out_channels, out_channels=img_channels, kernel=kernel_size)
+
+    def forward(self, x: Tensor, time_emb: Tensor, text_emb: Tensor) -> Tensor:
+        te = ops.cast(time_emb, torch.float32)
+        tx = None if text_emb is None else ops.cast(text_emb, torch.float32)
+        return ops.from_nhwc(unet_expert_bank_forward([self], ops.to_nhwc(x), te, tx, None))
+
+
+class Vit_block(nn.Module):
+    """DiffiT-style block: GN -> silu -> linear -> LN -> TMSA -> LN -> MLP with MP residuals
+    (reference model_components.py:435-562)."""
+
+    def __init__(self, num_heads: int, num_groups: int, num_channels: int, seq_ln: int, emb_dim: int,
+                 resample: Optional[str] = "keep", time_dim: Optional[int] = 0, res_balance: Optional[float] = 0.5,
+                 attn_balance: Optional[float] = 0.5, gain_s: Optional[float] = 1.0, gain_t: Optional[float] = 1.0):
+        super().__init__()
+        self.res_balance = res_balance
+        self.gain_s = gain_s
+        self.gain_t = gain_t
+        self.emb_dim = emb_dim
+        self.resample = resample
+        self.GN = nn.GroupNorm(num_groups=num_groups, num_channels=num_channels)
+        self.skip_proj = m.MP_Conv(num_channels, emb_dim, kernel=()) if num_channels != emb_dim else None
+        self.linear1 = m.MP_Conv(num_channels, emb_dim, kernel=())
+        self.norm1 = nn.LayerNorm(emb_dim)
+        self.norm2 = nn.LayerNorm(emb_dim)
+        self.TMSA = m.MP_Attention(num_heads=num_heads, emb_dim=emb_dim, seq_ln=seq_ln, time_dim=time_dim,
+                                   attn_balance=attn_balance)
+        self.linear2 = m.MP_Conv(emb_dim, emb_dim * 4, kernel=())
+        self.linear3 = m.MP_Conv(emb_dim * 4, emb_dim, kernel=())
+
+    def forward(self, x: Tensor, time_embedding: Optional[Tensor] = None) -> Tensor:
+        if self.resample != "keep":
+            raise NotImplementedError("Vit_block: only resample='keep' is used by the reference models")
+        t = self.res_balance
+        n = ((1.0 - t) ** 2 + t ** 2) ** 0.5
+        res_main = x
+        h = ops.group_norm(x, self.GN.weight, self.GN.bias, self.GN.num_groups, ops.ACT_MP_SILU, self.GN.eps)
+        h = self.linear1._fwd(h, self.gain_s)
+        res_attn = h
+        y = ops.layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if time_embedding is not None and time_embedding.ndim == 2:
+            time_embedding = time_embedding[:, None, :]
+        y = self.TMSA(y, time_embedding=time_embedding, gain_s=self.gain_s, gain_t=self.gain_t)
+        y = ops.mp_sum(y, res_attn, t)
+        h = ops.layer_norm(y, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.mp_silu(self.linear2._fwd(h, self.gain_s))
+        h = self.linear3._fwd(h, self.gain_s, res=y, alpha=(1.0 - t) / n, beta=t / n)          # mp_sum(linear3(.), y, t)
+        if self.skip_proj is not None:
+            # mp_sum(skip_proj(res_main), h, t): the projection gets weight (1-t), h the weight t
+            return self.skip_proj._fwd(res_main, self.gain_s, res=h, alpha=(1.0 - t) / n, beta=t / n)
+        return ops.mp_sum(res_main, h, t)
+
+
+class Vit_expert(nn.Module):
+    """Isotropic ViT expert with a per-expert patch size (reference model_components.py:564-706)."""
+
+    def __init__(self, num_heads: int, num_groups: int, in_channels: int, seq_ln: int, emb_dim: int, num_blocks: int,
+                 patch_size: int, time_dim: Optional[int] = 0, text_dim: Optional[int] = 0, res_balance: Optional[float] = 0.5,
+                 attn_balance: Optional[float] = 0.5, emb_balance: Optional[float] = 0.5, gain_s: Optional[float] = 1.0,
+                 gain_t: Optional[float] = 1.0):
+        super().__init__()
+        self.seq_ln = seq_ln
+        self.emb_balance = emb_balance
+        self.emb_dim = emb_dim
+        self.patch = nn.Conv2d(in_channels=in_channels, out_channels=emb_dim, kernel_size=patch_size, stride=patch_size)
+        self.map_txt = m.MP_Conv(in_channels=text_dim, out_channels=time_dim, kernel=()) \
+            if text_dim != time_dim and text_dim != 0 else None
+        self.pos_emb = nn.Parameter(torch.zeros(1, seq_ln, emb_dim))
+        self.diffit = nn.ModuleList()
+        for _ in range(num_blocks):
+            self.diffit.append(Vit_block(num_heads=num_heads, num_groups=num_groups, num_channels=emb_dim, seq_ln=seq_ln,
+                                         emb_dim=emb_dim, resample="keep", time_dim=time_dim, res_balance=res_balance,
+                                         attn_balance=attn_balance, gain_s=gain_s, gain_t=gain_t))
+        self.norm = nn.LayerNorm(emb_dim)
+        self.unpatch_proj = m.MP_Conv(in_channels=emb_dim, out_channels=in_channels * (patch_size ** 2), kernel=())
+        self.unpatch = nn.PixelShuffle(upscale_factor=patch_size)
+
+    def _fwd(self, x: Tensor, time_emb: Optional[Tensor], text_emb: Optional[Tensor]) -> Tensor:
+        """x channel-last (B,H,W,C) -> (B,H,W,C)."""
+        B, H, W, C = x.shape
+        p = self.patch.kernel_size[0]
+        hp, wp = -(-H // p), -(-W // p)
+        assert hp * wp == self.seq_ln, f"Sequence length mismatch: Got {hp * wp}, expected {self.seq_ln}, shape: {(B, self.emb_dim, hp, wp)}"
+        tok = ops.patch_embed(x, self.patch.weight, self.patch.bias)              # zero-pad + strided conv + bias
+        tok = ops.bias_add(tok, self.pos_emb)
+        if time_emb is not None:
+            time_emb = ops.cast(time_emb, torch.float32)
+        if text_emb is not None:
+            text_emb = ops.cast(text_emb, torch.float32)
+            if self.map_txt is not None:
+                if text_emb.ndim == 3:
+                    text_emb = ops.seq_mean(text_emb)
+                text_emb = self.map_txt._fwd(text_emb)
+            time_emb = ops.mp_sum(time_emb, text_emb, self.emb_balance)
+        for block in self.diffit:
+            tok = block(tok, time_embedding=time_emb)
+        tok = ops.layer_norm(tok, self.norm.weight, self.norm.bias, self.norm.eps)
+        tok = self.unpatch_proj._fwd(tok)
+        return ops.pixel_shuffle_tokens(tok, H, W, C, p)
+
+    def forward(self, x: Tensor, time_emb: Tensor = None, text_emb: Optional[Tensor] = None) -> Tensor:
+        return ops.from_nhwc(self._fwd(ops.to_nhwc(x), time_emb, text_emb))

@@ -1,0 +1,60 @@
+"""HDMOEM with a learned Scaling_router and soft query/context swap -- drop-in for the reference's
+``models/model_config1.py``."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from hdmoe_hip import ops
+from models._assembly import _HDMOEMBase, _PrecondBase, router_to_unet_experts   # noqa: F401  (re-exported helper)
+
+Tensor = torch.Tensor
+
+
+class HDMOEM(_HDMOEMBase):
+    """Reference model_config1.py:42-309: scaling factors from ``scaling_net`` (rows sum to 2); the stronger path
+    becomes the attention query: w = sigmoid(alpha_routing * (s_vit - s_unet))."""
+
+    _has_scaling_net = True
+
+    def _scaling(self, time_vec, time_embed, zeta, alpha_routing=10):
+        sf = self.scaling_net(x=time_embed, zeta=zeta)                       # (B, 2): [:, 0] ViT, [:, 1] U-Net
+        return sf[:, 0], sf[:, 1], sf
+
+    def _fusion_inputs(self, fu, fv, s_vit, s_unet, alpha_routing=10):
+        sw = ops.sigmoid(ops.axpby(s_vit, s_unet, 1.0, -1.0), float(alpha_routing))     # (B,)
+        d = ops.scale_rows(ops.axpby(fv, fu, 1.0, -1.0), sw)                # sw * (fv - fu)
+        return ops.axpby(fu, d, 1.0, 1.0), ops.axpby(fv, d, 1.0, -1.0)     # query, context (:282-283)
+
+    def forward(self, x: Tensor, time_vec: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor,
+                zeta: float, alpha_routing: float = 10):
+        res = self._fwd(ops.to_nhwc(ops.cast(x, torch.float32)), time_vec, text_emb, Unet_router_mask, Vit_router_mask, zeta,
+                        alpha_routing=alpha_routing)
+        return self._public(res)
+
+
+class preconditioned_HDMOEM(_PrecondBase):
+    """Reference model_config1.py:312-468."""
+
+    _net_cls = HDMOEM
+
+    def __init__(self, IN_in_channels: int, IN_img_resolution: int, internal_channels: int, time_emb_dim: int,
+                 text_emb_dim: int, num_experts: int, top_k: int, Fourier_bandwidth: float, VIT_num_blocks: int,
+                 VIT_patch_sizes: List[int], VIT_num_groups: int, VIT_num_heads: int, VIT_emb_size: int, Unet_num_blocks: int,
+                 Unet_channel_mult: list, Unet_kernel_sizes: List[Tuple[int, int]], Unet_model_channels: Optional[int] = 192,
+                 Unet_channel_mult_emb: Optional[int] = None, Unet_label_balance: Optional[float] = 0.5,
+                 Unet_concat_balance: Optional[float] = 0.5, sigma_data: Optional[float] = 0.5,
+                 log_var_channels: Optional[int] = 128):
+        super().__init__(sigma_data=sigma_data, log_var_channels=log_var_channels, IN_in_channels=IN_in_channels,
+                         IN_img_resolution=IN_img_resolution, internal_channels=internal_channels, time_emb_dim=time_emb_dim,
+                         text_emb_dim=text_emb_dim, num_experts=num_experts, top_k=top_k, Fourier_bandwidth=Fourier_bandwidth,
+                         VIT_num_blocks=VIT_num_blocks, VIT_patch_sizes=VIT_patch_sizes, VIT_num_groups=VIT_num_groups,
+                         VIT_num_heads=VIT_num_heads, VIT_emb_size=VIT_emb_size, Unet_num_blocks=Unet_num_blocks,
+                         Unet_channel_mult=Unet_channel_mult, Unet_kernel_sizes=Unet_kernel_sizes,
+                         Unet_model_channels=Unet_model_channels, Unet_channel_mult_emb=Unet_channel_mult_emb,
+                         Unet_label_balance=Unet_label_balance, Unet_concat_balance=Unet_concat_balance)
+
+    def forward(self, x: Tensor, sigma: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor, zeta: float,
+                return_log_var: bool = False):
+        return self._forward(x, sigma, text_emb, Unet_router_mask, Vit_router_mask, zeta, return_log_var)

@@ -1,0 +1,153 @@
+/* libhdmoe_hip.so -- C ABI of the MI355X (gfx950) kernels behind the HDMOEM denoising hot path.
+ *
+ * The reference (cs2mosa/Heterogeneous-MOE-for-Diffusion-models) is pure PyTorch: it has no FFI / operator
+ * registry, its "interface" for this path is the ATen call sequence inside models/model_internals.py,
+ * models/model_components.py and models/model_config{1,2}.py.  Each entry point below replaces one such
+ * sequence (cited as reference file:line); the Python nn.Module mirror in
+ * heterogeneous-moe-for-diffusion-models_amd/models/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless the comment says "host array".
+ *   - activations are NHWC / [rows][C] contiguous; `dtype` (HDMOE_F32 | HDMOE_BF16) is their element type.
+ *     Statistics, per-sample scalars, (B,F) embeddings, parameters and parameter gradients are fp32.
+ *   - `stream` is a hipStream_t (void*); kernels are enqueued on it, nothing syncs, allocates or frees,
+ *     so every call is hipGraph-capturable.  Scratch / accumulators are caller-provided.
+ *   - return 0 on success, HDMOE_EINVAL / HDMOE_EDTYPE / HDMOE_ELAUNCH (<0) otherwise; never throws.
+ *   - "grouped": rows of one launch belong to up to HDMOE_MAX_GROUPS experts; seg[g]..seg[g+1] (device int32)
+ *     is the row range of expert g; per-group kernel sizes come as host arrays of length ngroups.
+ */
+#ifndef HDMOE_H
+#define HDMOE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef HDMOE_OK
+#define HDMOE_OK 0
+#define HDMOE_EINVAL (-1)
+#define HDMOE_EDTYPE (-2)
+#define HDMOE_ELAUNCH (-3)
+#define HDMOE_F32 0
+#define HDMOE_BF16 1
+#define HDMOE_MAX_GROUPS 8
+#endif
+
+typedef void* hdmoe_stream_t; /* hipStream_t */
+#ifdef __HIPCC__
+#define HS hipStream_t
+#else
+#define HS hdmoe_stream_t
+#endif
+
+int hdmoe_version(void);
+
+/* ---- K3: MP_Conv = weight prep + implicit-GEMM conv  (model_internals.py:253-275) ------------------------ */
+/* w_raw/gain_ptr/kh/kw: host arrays [ngroups].  wf: [g][tap][O][Ipad]; wd (optional): [g][tap'][I][Opad]
+ * (tap' flipped when flip=1: the dgrad operand).  normalize=0: plain nn.Conv2d weight (Vit_expert.patch).
+ * mutate=1: training-mode forced weight normalisation, written back into w_raw (:254-256). */
+int hdmoe_wprep_fwd(float* const* w_raw, const float* const* gain_ptr, float gain_val, const int* kh, const int* kw,
+                    int ngroups, int O, int I, int Ipad, int Opad, void* wf, long wf_stride, void* wd, long wd_stride,
+                    int normalize, int mutate, int flip, int dtype, HS stream);
+/* G: per-group [tap][O][I] fp32 gradient w.r.t. the effective weight (from hdmoe_conv_wgrad);
+ * dw: per-group (O,I,kh,kw) fp32; dgain: per-group scalar accumulators or NULL. */
+int hdmoe_wprep_bwd(const float* const* w_raw, const float* const* gain_ptr, float gain_val, const float* const* G,
+                    float* const* dw, float* const* dgain, const int* kh, const int* kw, int ngroups, int O, int I,
+                    int normalize, HS stream);
+/* y = alpha*conv(x, w) + beta*res.  x [N][H][W][Cphys]; logical Cin = Cphys (+1 implicit all-ones channel when
+ * ones=1: Unet_expert's torch.cat([x, ones]), model_components.py:416); y [N][Ho][Wo][Cstore], Cstore <= Cout.
+ * Also runs dgrad (w = wd, pads flipped) and every F.linear (H = W = 1 or N = 1). */
+int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float alpha, float beta, const int* seg,
+                   int ngroups, long wstride, int N, int H, int W, int Ho, int Wo, int Cin, int Cphys, int Ipad, int Cout,
+                   int Cstore, int stride, int ones, const int* kh, const int* kw, const int* pt, const int* pl, int dtype,
+                   HS stream);
+/* G[g] ([tap][Cout][Cin] fp32, pre-zeroed) += dy^T * shifted(x); G: host array of device pointers. */
+int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W,
+                     int Ho, int Wo, int Cin, int Cphys, int Cout, int stride, int ones, const int* kh, const int* kw,
+                     const int* pt, const int* pl, int dtype, HS stream);
+
+/* ---- K4/K7: pointwise, broadcast, relayout  (model_internals.py:33-127, model_components.py:232-253) ----- */
+int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, HS stream);      /* a*x + b*y (y may be NULL) : mp_sum */
+int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, HS stream);                     /* a*x + c */
+int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, HS stream);
+int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
+int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, HS stream);
+int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, HS stream);
+int hdmoe_sigmoid_fwd(void* out, const void* x, float a, long n, int dtype, HS stream);                         /* sigmoid(a*x) */
+int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, int dtype, HS stream);
+int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, HS stream);  /* mp_silu(u * e[n][c]) */
+int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
+                        int dtype, HS stream);                                                                   /* de accumulates */
+int hdmoe_scale_rows_fwd(void* out, const void* x, const float* s, long rows, long L, int dtype, HS stream);    /* out[r][:] = s[r]*x[r][:] */
+int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, const float* s, long rows, long L,
+                         int dtype, HS stream);                                                                  /* dx and/or ds (accumulates) */
+int hdmoe_cat2_fwd(void* out, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows, int dtype, HS stream); /* mp_cat */
+int hdmoe_cat2_bwd(void* da, void* db, const void* dout, float wa, float wb, int Ca, int Cb, long rows, int dtype, HS stream);
+int hdmoe_pool2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, HS stream);      /* resample 'down' (scale .25) / bwd of 'up' (1) */
+int hdmoe_upsample2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, HS stream);  /* resample 'up' (1) / bwd of 'down' (.25) */
+int hdmoe_seq_reduce(float* out, const void* x, int N, long S, int C, float scale, int dtype, HS stream);        /* out[n][c] += scale*sum_s x[n][s][c] */
+int hdmoe_seq_bcast_add(void* out, const void* x, const float* t, int N, long S, int C, float scale, int dtype, HS stream);
+int hdmoe_bias_add(void* out, const void* x, const float* bias, long rows, long L, int dtype, HS stream);
+int hdmoe_colsum(float* out, const void* dy, long rows, long L, int dtype, HS stream);                          /* accumulates */
+int hdmoe_lerp_param_fwd(void* out, const void* a, const void* b, const float* alpha, long n, int dtype, HS stream);   /* model_config2.py:291 */
+int hdmoe_lerp_param_bwd(void* da, void* db, float* dalpha, const void* g, const void* a, const void* b,
+                         const float* alpha, long n, int dtype, HS stream);
+int hdmoe_gate_mix_fwd(void* out, float* gate, const void* logits, const void* U, const void* A, long rows, int C,
+                       int dtype, HS stream);                                                                    /* model_config2.py:297-301 */
+int hdmoe_gate_mix_bwd(void* dU, void* dA, void* dlogits, const void* dout, const float* dgate, const float* gate,
+                       const void* U, const void* A, long rows, int C, int dtype, HS stream);
+int hdmoe_softmax_rows_fwd(float* out, const float* x, long rows, int C, float scale, HS stream);               /* model_components.py:64 */
+int hdmoe_softmax_rows_bwd(float* dx, const float* dy, const float* y, long rows, int C, float scale, HS stream);
+int hdmoe_nchw_to_nhwc(void* out, const float* x, const float* s, int N, int C, long HW, int dtype, HS stream);  /* + per-sample scale (c_in) */
+int hdmoe_nhwc_to_nchw(float* out, const void* F, const float* sf, const float* x, const float* sx, int N, int C,
+                       long HW, int dtype, HS stream);                                                           /* sf*F + sx*x : D_x, model_config2.py:449 */
+int hdmoe_patch_relayout(void* out, const void* in, int N, int H, int W, int C, int p, int hp, int wp, int order,
+                         int to_img, int dtype, HS stream);                                                      /* PixelShuffle / patchify */
+int hdmoe_fourier(float* out, const float* x, const float* freqs, const float* phases, int B, int F, HS stream); /* model_internals.py:171-174 */
+int hdmoe_edm_coeffs(float* coef, const float* sigma, int nsig, float sigma_data, int B, HS stream);             /* model_config2.py:431-438 */
+int hdmoe_sigmoid_scaling(float* sv, float* su, float* pair, const float* c_noise, float tp, float soft, int B, HS stream); /* :244-249 */
+int hdmoe_adaln_fwd(float* out, const float* x, const float* cond, long B, int F, HS stream);                   /* model_components.py:148-151 */
+int hdmoe_adaln_bwd(float* dx, float* dcond, const float* g, const float* x, const float* cond, long B, int F, HS stream);
+int hdmoe_take_col_pos_fwd(float* out, const float* w, long B, int E, int e, HS stream);                         /* w[:,e] where > 0 (model_config1.py:26,35) */
+int hdmoe_take_col_pos_bwd(float* dw, const float* g, const float* w, long B, int E, int e, HS stream);          /* dw pre-zeroed */
+int hdmoe_dropout(void* out, const void* x, unsigned long long seed, float p, long n, int dtype, HS stream);     /* F.dropout, model_components.py:245-246 */
+int hdmoe_randn(float* out, unsigned long long seed, float scale, long n, HS stream);                            /* randn*zeta, :155-156 */
+
+/* ---- K6: norms  (model_internals.py:8-30; nn.GroupNorm / nn.LayerNorm in model_components.py) ------------ */
+int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, HS stream);               /* h = mp_silu(xn), optional */
+int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, int dtype, HS stream);
+int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int N,
+                        long S, int C, int G, int act, float eps, int dtype, HS stream);                         /* act: 0 none, 1 relu, 2 mp_silu */
+int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x,
+                        const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
+                        int G, int act, int dtype, HS stream);                                                   /* ws: 2*N*G floats */
+int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
+                        int C, float eps, int dtype, HS stream);
+int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, const void* x, const float* gamma,
+                        const float* mean, const float* rstd, long rows, int C, int dtype, HS stream);
+
+/* ---- K5: attention core  (model_internals.py:374-404) -------------------------------------------------------- */
+int hdmoe_attn_fwd(void* out, float* lse, const void* q, const void* k, const void* v, const float* bias, int B, int Sq,
+                   int Skv, int H, int D, int Sb, int dtype, HS stream);
+int hdmoe_attn_bwd(void* dq, void* dk, void* dv, float* dbias, float* delta, const void* dout, const void* out,
+                   const void* q, const void* k, const void* v, const float* lse, const float* bias, int B, int Sq,
+                   int Skv, int H, int D, int Sb, int dtype, HS stream);
+
+/* ---- K1/K2: router head + dispatch  (model_components.py:155-168, model_config1.py:11-39) ---------------------- */
+int hdmoe_router_head_fwd(float* sparse, float* probs, float* xout, int* idx, const float* logits, const float* noise,
+                          const float* mask, long B, int E, int k, HS stream);
+int hdmoe_router_head_bwd(float* dlogits, const float* dsparse, const float* dprobs, const float* dxout,
+                          const float* sparse, const float* probs, const int* idx, const float* mask, long B, int E, int k,
+                          HS stream);
+int hdmoe_dispatch_plan(int* perm, int* row_expert, float* row_w, int* inv, int* seg, const float* sparse, int B, int E,
+                        int kcap, HS stream);
+int hdmoe_gather_rows(void* dst, const void* src, const int* perm, long R, long L, int dtype, HS stream);
+int hdmoe_combine_rows_fwd(void* out, const void* ys, const int* inv, const float* row_w, long B, int kcap, long L,
+                           int dtype, HS stream);
+int hdmoe_combine_rows_bwd(void* dys, float* dsparse, const void* dout, const void* ys, const int* perm,
+                           const int* row_expert, const float* row_w, long R, int E, long L, int dtype, HS stream);
+
+#undef HS
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDMOE_H */
