@@ -33,11 +33,25 @@ def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
     torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol, equal_nan=True, msg=None if not msg else (lambda m: msg + ": " + m))
 
 
-def close_scaled(a, b, rel, msg=""):
+def close_scaled(a, b, rel, msg="", atol=1e-6, outlier_frac=0.0):
+    """max|a-b| <= rel * max|b| + atol over the finite entries; non-finite entries (masked -inf logits, NaN rows)
+    must coincide.  `outlier_frac` tolerates that share of elements beyond the bound (bf16 ReLU-mask flips)."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    scale = max(float(b.abs().max()), 1e-6)
-    err = float((a - b).abs().max())
-    assert err <= rel * scale, f"{msg}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin), f"{msg}: non-finite pattern differs"
+    assert torch.equal(a[~fin].nan_to_num(7.0), b[~fin].nan_to_num(7.0)), f"{msg}: non-finite values differ"
+    if not bool(fin.any()):
+        return
+    a, b = a[fin], b[fin]
+    scale = float(b.abs().max())
+    diff = (a - b).abs()
+    bound = rel * scale + atol
+    if outlier_frac > 0:
+        frac = float((diff > bound).float().mean())
+        assert frac <= outlier_frac, f"{msg}: {frac:.2%} of elements beyond {bound:.3e}"
+        return
+    err = float(diff.max())
+    assert err <= bound, f"{msg}: max err {err:.3e} > {rel:.1e} * {scale:.3e} + {atol:.0e}"
 
 
 def load_into(mod, state):
@@ -467,6 +481,7 @@ def test_norms_vs_torch(dtype, rel):
     torch.manual_seed(9)
     for (N, S, C, G, act) in [(3, 64, 32, 4, ops.ACT_MP_SILU), (2, 1024, 64, 1, ops.ACT_RELU), (4, 1, 48, 1, ops.ACT_RELU)]:
         x, gm, bt, go = torch.randn(N, S, C) + 0.3, 1 + 0.2 * torch.randn(C), 0.2 * torch.randn(C), torch.randn(N, S, C)
+        x, go = x.to(dtype).float(), go.to(dtype).float()          # both sides see the same (rounded) inputs
         xr, gr, br = x.clone().requires_grad_(True), gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
         z = F.group_norm(xr.transpose(1, 2), G, gr, br).transpose(1, 2)
         ref = F.relu(z) if act == ops.ACT_RELU else F.silu(z) / 0.596
@@ -475,8 +490,9 @@ def test_norms_vs_torch(dtype, rel):
         gd, bd = gm.to(DEV).requires_grad_(True), bt.to(DEV).requires_grad_(True)
         out = ops.group_norm(xd, gd, bd, G, act)
         out.backward(go.to(DEV).to(dtype))
+        fl = 2e-3 if (dtype == torch.bfloat16 and act == ops.ACT_RELU) else 0.0     # rounding can flip a ReLU mask bit
         close_scaled(out, ref, rel, msg="gn out")
-        close_scaled(xd.grad, xr.grad, rel, msg="gn dx")
+        close_scaled(xd.grad, xr.grad, rel, msg="gn dx", outlier_frac=fl)
         close_scaled(gd.grad, gr.grad, rel, msg="gn dgamma")
         close_scaled(bd.grad, br.grad, rel, msg="gn dbeta")
     x, gm, bt, go = torch.randn(70, 32), 1 + 0.2 * torch.randn(32), 0.2 * torch.randn(32), torch.randn(70, 32)
