@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- denoise-steps/sec (fwd + EDM_LOSS + bwd) of the HDMOEM hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): models.model_config1.preconditioned_HDMOEM, reference Utils/configs.py shapes
+(internal_channels 32, R = 32, 4 experts [3x3,3x3,5x5,5x5] / ViT patches [4,8,8,16]) with top_k = 2, synthetic 4x32x32
+latents, per-GPU batch 256, bf16 experts / fp32 stem + router trunks, train() mode (dropout, logit noise, forced weight
+normalisation all run).  One step = forward + fused EDM_LOSS + backward (+ gradient all-reduce when N > 1), weak scaling.
+Prints ONE JSON line on rank 0.  Only the `cpu_baseline` leg touches oracle/ (the CPU restatement, timed as a baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "heterogeneous-moe-for-diffusion-models_amd")
+for p in (PKG, os.path.join(PKG, "Utils"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK = {"bfloat16": 2500.0, "float32": 157.3}     # dense TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(cfg_id, device):
+    import hdmoe_hip
+    import configs as C
+    from models import model_config1, model_config2
+    bc = C.BASELINE_CONFIGS[cfg_id]
+    kw = C.model_kwargs(**bc["over"])
+    mod = model_config1 if bc["module"] == 1 else model_config2
+    torch.manual_seed(1234)                                  # identical replicas on every rank
+    model = mod.preconditioned_HDMOEM(**kw)
+    with torch.no_grad():                                    # zero-inits would make the experts' output identically 0
+        for n, p in model.named_parameters():
+            if n.endswith("out_gain"):
+                p.fill_(0.5)
+            elif n.endswith("alpha_txt"):
+                p.fill_(0.3)
+    hdmoe_hip.set_compute_dtype(torch.bfloat16 if bc["dtype"] == "bf16" else torch.float32)
+    return model.to(device).train(), kw, bc
+
+
+def make_inputs(kw, B, device, seed, module):
+    """Seeded synthetic step inputs mirroring reference Utils/training.py:125-153."""
+    import utils as U
+    g = torch.Generator(device=device).manual_seed(seed)
+    R, Cl = kw["IN_img_resolution"], kw["IN_in_channels"]
+    x0 = 0.5 * torch.randn(B, Cl, R, R, device=device, generator=g)
+    sigma = U.sample_sigma_hybrid(B, 0.002, 80.0, p_mean=-1.2, p_std=1.6, extreme_prob=0.5, device=device, generator=g)
+    x = x0 + sigma * torch.randn(B, Cl, R, R, device=device, generator=g)
+    text = torch.randn(B, 77, kw["text_emb_dim"], device=device, generator=g)
+    ones = torch.ones(B, kw["num_experts"], device=device)
+    extra = dict(transition_point=-1.2, softness=1.6) if module == 2 else {}
+    return dict(x0=x0, sigma=sigma, x=x, text=text, um=ones, vm=ones, extra=extra)
+
+
+def conv_flops(info):
+    """Algorithmic FLOPs of one conv / dgrad / wgrad launch from the REALISED per-expert row counts."""
+    per_px = 2.0 * info["HW"] * info["O"] * info["I"]
+    if info["seg"] is None:
+        return info["N"] * per_px * info["taps"][0]
+    seg = info["seg"].tolist()
+    return sum((seg[g + 1] - seg[g]) * per_px * t for g, t in enumerate(info["taps"]))
+
+
+def roofline_leg(step_fn, n_steps):
+    """Time every conv-family launch of a few extra steps with events on the launch stream; report the kernel
+    instantiation with the largest total time.  achieved = sum(algorithmic FLOPs) / sum(duration)."""
+    from hdmoe_hip import ops
+    ops.PROFILE = []
+    for _ in range(n_steps):
+        step_fn()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for kind, info, s, e in rec:
+        tname = "float" if info["dtype"] == "float32" else "__bf16"
+        name = f"conv_fwd_kernel<{tname}, {info['nb']}, {'true' if info['vec'] else 'false'}>" if kind == "conv_fwd" \
+            else f"conv_wgrad_kernel<{tname}>"
+        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, n=0, dtype=info["dtype"]))
+        a["ms"] += s.elapsed_time(e)
+        a["flops"] += conv_flops(info)
+        a["n"] += 1
+    if not agg:
+        return None, {}
+    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    peak = MFMA_PEAK[a["dtype"]]
+    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    table = {k: dict(launches_per_step=v["n"] / n_steps, avg_us=1e3 * v["ms"] / v["n"], ms_per_step=v["ms"] / n_steps,
+                     tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in agg.items()}
+    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                traffic=None, avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps,
+                method="HIP events around each launch on the launch stream (includes ~launch gap); see profiles/"), table
+
+
+def cpu_baseline(cfg_id, kw, module, seconds=20.0):
+    """The CPU oracle (port of the reference algorithm) timed on the host cores on a bounded sample: B = 8 samples per
+    step, eval-mode fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
+    from oracle import hdmoe_oracle as O
+    import configs as C
+    from models import model_config1, model_config2
+    torch.manual_seed(1234)
+    mod = model_config1 if module == 1 else model_config2
+    model = mod.preconditioned_HDMOEM(**kw)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("out_gain"):
+                p.fill_(0.5)
+            elif n.endswith("alpha_txt"):
+                p.fill_(0.3)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k.split(".")[-1] not in ("freqs", "phases"))
+         for k, v in model.state_dict().items()}
+    cfg = dict(internal_channels=kw["internal_channels"], VIT_num_heads=kw["VIT_num_heads"], VIT_num_groups=kw["VIT_num_groups"],
+               top_k=kw["top_k"], sigma_data=kw["sigma_data"])
+    B = 8
+    inp = make_inputs(kw, B, "cpu", 99, module)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lc = C.loss_configs
+    times = []
+    t_end = time.time() + seconds
+    while time.time() < t_end or len(times) < 2:
+        t0 = time.time()
+        out = O.preconditioned_hdmoem(P, cfg, module, inp["x"], inp["sigma"], inp["text"], inp["um"], inp["vm"],
+                                      return_log_var=True, **inp["extra"])
+        loss = O.edm_loss(out, inp["x0"], kw["num_experts"], lc["unet_bal"], lc["vit_bal"], lc["z_bal"])["loss"]
+        loss.backward()
+        for v in P.values():
+            v.grad = None
+        times.append(time.time() - t0)
+        if len(times) >= 12:
+            break
+    med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return med, B, cores, len(times)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (2 = headline single-GPU workload)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", default="", help="write the per-kernel table of the roofline leg to this JSON file")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    import hdmoe_hip
+    from hdmoe_hip.dp import GradBuckets
+    import configs as C
+    import utils as U
+    hdmoe_hip.lib()
+    hdmoe_hip.manual_seed(4321 + rank)
+    model, kw, bc = build_model(args.config, device)
+    B = args.batch or bc["batch"]
+    inp = make_inputs(kw, B, device, 1234 + rank, bc["module"])
+    lc = C.loss_configs
+    crit = U.EDM_LOSS(num_experts=kw["num_experts"], sigma_data=kw["sigma_data"], Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"],
+                      z_bal=lc["z_bal"], prior_bal=lc["prior_bal"])
+    buckets = GradBuckets(model, bucket_mb=16.0)            # flat fp32 grad buckets; RCCL all-reduce when world > 1
+    zeta = 0.1
+
+    def step():
+        buckets.zero_grad()
+        out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["um"], Vit_router_mask=inp["vm"],
+                    zeta=zeta, return_log_var=True, **inp["extra"])
+        loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+        loss["loss"].backward()
+        buckets.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1e3 * dt / args.steps
+    loss_val = float(loss["loss"])
+
+    roof, table = (None, {})
+    cpu = None
+    if rank == 0:
+        if not args.no_roofline:
+            roof, table = roofline_leg(step, 3)
+            if args.dump_kernels:
+                with open(args.dump_kernels, "w") as f:
+                    json.dump(table, f, indent=1)
+        if world == 1 and not args.no_cpu_baseline:
+            med, cb, cores, nst = cpu_baseline(args.config, kw, bc["module"])
+            # metric unit: steps of B samples per second -> a CPU step of cb samples counts as cb/B of a bench step
+            cpu = dict(value=round((cb / med) / B, 5), unit="denoise-steps/sec", cores=cores, kind="port",
+                       sample=f"CPU oracle, fp32, eval-mode fwd+loss+bwd on B={cb} samples/step, median of {nst - 1} steps "
+                              f"({med:.2f} s/step = {cb / med:.2f} samples/s), scaled to the bench's {B}-sample step")
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        line = {
+            "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4) if False else round(1e3 / ms * 1.0, 4),
+            "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bc["dtype"] == "bf16" else "f32",
+            "data": "synthetic", "samples_per_sec": round(world * B * 1e3 / ms, 1),
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: model_config{bc['module']} preconditioned_HDMOEM, "
+                                   f"{kw['IN_in_channels']}x{kw['IN_img_resolution']}x{kw['IN_img_resolution']} latents, "
+                                   f"{kw['num_experts']} experts top-{kw['top_k']}, per-GPU batch {B}, train mode",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "step": "fwd + EDM_LOSS + bwd"
+                       + (" + RCCL grad all-reduce" if world > 1 else ""), "optimizer": "excluded (metric is fwd+bwd)",
+                       "router_dtype": "f32", "loss": round(loss_val, 5), "grad_bytes": buckets.nbytes()},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        # whole-job throughput: every rank runs one B-sample step per step time (weak scaling) -> steps/s aggregate = world / t
+        line["value"] = round(world * 1e3 / ms, 4)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""Data-parallel gradient exchange for the HDMOEM replicas: one process per GPU, flat fp32 gradient buckets whose
+views ARE the parameters' ``.grad`` tensors, one RCCL all-reduce(avg) per bucket over xGMI launched from autograd hooks
+as soon as the bucket's last gradient lands (overlaps the rest of backward).
+
+Sample routing is per-sample and every expert is replicated, so the path has no data-path collective: the only exchange
+is this gradient all-reduce.  An expert that received no sample on a rank contributes exact
+zeros (its bucket slice was memset and never written) so every rank reduces identical layouts.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()                                           # backward produces gradients roughly in this order
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets: List[torch.Tensor] = []
+        self._members: List[List[torch.nn.Parameter]] = []
+        cur, n = [], 0
+        for p in params:
+            if cur and n + p.numel() > cap:
+                self._seal(cur, n)
+                cur, n = [], 0
+            cur.append(p)
+            n += p.numel()
+        if cur:
+            self._seal(cur, n)
+        self._pending = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
+        self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        for bi, members in enumerate(self._members):
+            for p in members:
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+
+    def _seal(self, members, n):
+        p0 = members[0]
+        flat = torch.zeros(n, dtype=torch.float32, device=p0.device)
+        off = 0
+        for p in members:
+            p.grad = flat[off:off + p.numel()].view_as(p)           # gradient_as_bucket_view
+            off += p.numel()
+        self.buckets.append(flat)
+        self._members.append(list(members))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._pending[bi] += 1
+            if self._pending[bi] == len(self._members[bi]):
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        if self.world == 1 or self._works[bi] is not None:
+            return
+        if self._backend == "nccl":                               # "nccl" is RCCL on ROCm
+            self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:                                                       # gloo (CPU tests): no AVG
+            self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Call after backward: reduce buckets whose hooks did not all fire (unused experts), wait for all."""
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for bi, w in enumerate(self._works):
+            if w is not None:
+                w.wait()
+                if self._backend != "nccl":
+                    self.buckets[bi].div_(self.world)
+            self._works[bi] = None
+            self._pending[bi] = 0
+
+    def zero_grad(self):
+        for flat in self.buckets:
+            flat.zero_()
+
+    def nbytes(self) -> int:
+        return sum(b.numel() for b in self.buckets) * 4

@@ -50,6 +50,29 @@ def _next_seed() -> int:
 # =====================================================================================================
 # MP_Conv: weight prep + implicit GEMM conv (+dgrad, wgrad)
 # =====================================================================================================
+# Optional per-launch timing of the GEMM-shaped kernels (bench.py's roofline leg): when PROFILE is a list, every
+# hdmoe_conv_fwd / hdmoe_conv_wgrad launch is bracketed by events on the launch stream and logged with its shape.
+PROFILE = None
+
+
+def _timed(kind: str, info: dict, name: str, *args):
+    if PROFILE is None:
+        call(name, *args)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    call(name, *args)
+    e.record()
+    PROFILE.append((kind, info, s, e))
+
+
+def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
+    esz = x.element_size()
+    vec = cphys % (16 // esz) == 0
+    nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
+    return dict(dtype=str(x.dtype).replace("torch.", ""), seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)],
+                nb=nb, vec=vec)
+
 def _kernel_hw(w: Tensor):
     if w.ndim == 4:
         return int(w.shape[2]), int(w.shape[3])
@@ -87,8 +110,8 @@ class _MPConvFn(torch.autograd.Function):
         call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, 16, wf, wstride, None, 0,
              1 if normalize else 0, 1 if training else 0, 0, _dt(x))
         y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
-        call("hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta, seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1,
-             1 if ones else 0, khs, kws, pts, pts, _dt(x))
+        _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
+               seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
         ctx.save_for_backward(x, seg, *tensors)
         ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None)
         return y
@@ -119,8 +142,8 @@ class _MPConvFn(torch.autograd.Function):
             pt_d = [kh - 1 - p for kh, p in zip(khs, pts)]
             pl_d = [kw - 1 - p for kw, p in zip(kws, pts)]
             # dgrad: conv over dy (O channels) with the flipped kernel; logical out channels I, stored Cphys
-            call("hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0, seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0,
-                 khs, kws, pt_d, pl_d, _dt(x))
+            _timed("conv_fwd", _conv_info(dy, seg, N, H, W, I, O, Cphys, khs, kws, O), "hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0,
+                   seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0, khs, kws, pt_d, pl_d, _dt(x))
         if has_res and nig[1]:
             dres = torch.empty_like(dy)
             call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
@@ -128,8 +151,8 @@ class _MPConvFn(torch.autograd.Function):
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w:
             Gs = [torch.zeros((khs[g] * kws[g], O, I), dtype=torch.float32, device=x.device) for g in range(G)]
-            call("hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts,
-                 _dt(x))
+            _timed("conv_wgrad", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W,
+                   Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
             dws = [torch.empty_like(w) for w in weights]
             if need_gain:
                 dgs = [torch.zeros((), dtype=torch.float32, device=x.device) for _ in range(G)]
@@ -1127,3 +1150,44 @@ def sigmoid_scaling(c_noise: Tensor, transition_point: float, softness: float):
     pair = torch.empty((B, 2), dtype=torch.float32, device=c.device)
     call("hdmoe_sigmoid_scaling", sv, su, pair, c, float(transition_point), float(softness), B)
     return sv, su, pair
+
+
+# =====================================================================================================
+# EDM_LOSS (row N2: the step right after the path) -- fused, sync-free
+# =====================================================================================================
+class _EDMLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, denoised, target, log_var, pU, pV, rU, rV, cfg):
+        unet_bal, vit_bal, z_bal = cfg
+        d = _f32(denoised); t = _f32(target.detach())
+        B = d.shape[0]
+        L = d.numel() // B
+        E = pU.shape[1]
+        lv = None if log_var is None else _f32(log_var).reshape(-1)
+        pU, pV, rU, rV = _f32(pU), _f32(pV), _f32(rU), _f32(rV)
+        out = torch.empty(5, dtype=torch.float32, device=d.device)
+        aux = torch.empty(2 * E + 3, dtype=torch.float32, device=d.device)
+        sse = torch.empty(B, dtype=torch.float32, device=d.device)
+        call("hdmoe_edm_loss_fwd", out, aux, sse, d, t, lv, pU, pV, rU, rV, B, L, E, unet_bal, vit_bal, z_bal)
+        ctx.save_for_backward(d, t, lv, rU, rV, aux, sse)
+        ctx.meta = (B, L, E, cfg, None if log_var is None else log_var.shape)
+        stats = out.detach()
+        ctx.mark_non_differentiable(stats)
+        return out[0], stats
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        d, t, lv, rU, rV, aux, sse = ctx.saved_tensors
+        B, L, E, (unet_bal, vit_bal, z_bal), lv_shape = ctx.meta
+        g = _f32(g.reshape(1))
+        dD = torch.empty_like(d)
+        dlv = None if lv is None else torch.empty_like(lv)
+        dpU, dpV, drU, drV = (torch.empty_like(rU) for _ in range(4))
+        call("hdmoe_edm_loss_bwd", dD, dlv, dpU, dpV, drU, drV, g, aux, sse, d, t, lv, rU, rV, B, L, E, unet_bal, vit_bal, z_bal)
+        return dD, None, (None if dlv is None else dlv.reshape(lv_shape)), dpU, dpV, drU, drV, None
+
+
+def edm_loss(denoised: Tensor, target: Tensor, log_var: Optional[Tensor], pU: Tensor, pV: Tensor, rU: Tensor, rV: Tensor,
+             unet_bal: float, vit_bal: float, z_bal: float):
+    """Returns (loss 0-dim with grad, stats (5,) detached = [loss, denoising, balance, z_loss, pure_loss])."""
+    return _EDMLossFn.apply(denoised, target, log_var, pU, pV, rU, rV, (float(unet_bal), float(vit_bal), float(z_bal)))

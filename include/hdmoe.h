@@ -146,6 +146,15 @@ int hdmoe_combine_rows_fwd(void* out, const void* ys, const int* inv, const floa
 int hdmoe_combine_rows_bwd(void* dys, float* dsparse, const void* dout, const void* ys, const int* perm,
                            const int* row_expert, const float* row_w, long R, int E, long L, int dtype, HS stream);
 
+/* ---- N2 (next to the path): EDM_LOSS fused  (Utils/utils.py:127-172) ---------------------------------------------- */
+/* out[5] = loss, denoising, balance, z_loss, pure_loss; aux: 2E+3 floats kept for the backward; sse: B floats scratch */
+int hdmoe_edm_loss_fwd(float* out, float* aux, float* sse, const float* denoised, const float* target, const float* log_var,
+                       const float* pU, const float* pV, const float* rU, const float* rV, int B, long L, int E, float unet_bal,
+                       float vit_bal, float z_bal, HS stream);
+int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU, float* drV, const float* gin, const float* aux,
+                       const float* sse, const float* denoised, const float* target, const float* log_var, const float* rU,
+                       const float* rV, int B, long L, int E, float unet_bal, float vit_bal, float z_bal, HS stream);
+
 #undef HS
 #ifdef __cplusplus
 }
