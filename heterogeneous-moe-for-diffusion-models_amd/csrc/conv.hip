@@ -234,7 +234,7 @@ struct WgradArgs {
   const void* dy;      // [N][Ho][Wo][Cout]
   float* G[HDMOE_MAX_GROUPS];   // [tap][Cout][Cin] fp32, pre-zeroed
   const int* seg;
-  int N, H, W, Ho, Wo, Cin, Cphys, Cout, stride, ones, ngroups, spw, ob_count, ib_count;
+  int N, H, W, Ho, Wo, Cin, Cphys, Cout, stride, ones, ngroups, spw, ob_count, ib_count, tx0;
   int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
 };
 
@@ -331,6 +331,222 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     flush_wgrad<T, CPL>(acc, a.G[cur_g], tap, o0, i0, a.Cout, a.Cin, lane);
 }
 
+
+// ------------------------------------------------------------------ wgrad v2 (stride 1): LDS-staged tiles
+// A workgroup walks `upw` consecutive (sample, pixel-tile) units.  Per unit it stages the dy tile [128 px][OB] and the
+// x halo tile [(TH+kh-1)][(TW+kw-1)][32 ch] in LDS once (16-byte vectors); every tap then reads both from LDS.  Each of
+// the 4 waves owns the taps t = wave (mod 4) (k-steps instead, for 1x1 / linear layers) and keeps their [OB x 32]
+// accumulators in registers across all its units; one coalesced fp32 atomic flush per expert change / at the end.
+// The contraction runs over PIXELS, so both MFMA operands need 8 consecutive pixels of one channel per lane while the
+// tiles are stored [pixel][channel]: bf16 uses the hardware transposing read ds_read_b64_tr_b16 (two per fragment,
+// cdna_hip_programming.md T10), fp32 reads its single value per 32x32x2 MFMA with conflict-free ds_read_b32.
+constexpr int WG2_PT = 128;     // pixels per tile
+constexpr int WG2_IB = 32;      // input channels per workgroup
+
+template <typename T> DEVI void frag_set_raw(Frag8<T>& f, int j, T v);
+template <> DEVI void frag_set_raw<bf16>(Frag8<bf16>& f, int j, bf16 v) { f.v[j] = v; }
+template <> DEVI void frag_set_raw<float>(Frag8<float>& f, int j, float v) { f.v[j] = v; }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <typename T> struct VecW;                         // elements per 16-byte vector
+template <> struct VecW<bf16> { static constexpr int N = 8; };
+template <> struct VecW<float> { static constexpr int N = 4; };
+
+// bf16: fragment rows = pixels rowa (elements 0..3) and rowb (4..7) of this lane's 16-lane group; `col` = 16-bit column
+DEVI void load_frag_tr(Frag8<bf16>& f, const bf16* rowa, const bf16* rowb, int col) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(rowa + col));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(rowb + col));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  f.v = __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int OT, int MAXT, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, int TW, int tiles_y, int tiles_x, int upw, int units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int OB = 32 * OT;
+  constexpr int OBP = (OT == 2 && sizeof(T) == 2) ? OB + 32 : OB;      // bank-conflict-free row stride for the tr reads
+  constexpr int VW = VecW<T>::N;
+  constexpr int CPP = OB / VW;                                          // 16-B chunks per dy pixel
+  constexpr int XPP = WG2_IB / VW;                                      // 16-B chunks per x pixel
+  T* sdy = reinterpret_cast<T*>(smem_raw);                              // [WG2_PT][OBP]
+  T* sx = sdy + WG2_PT * OBP;                                           // [halo rows][halo cols][WG2_IB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q4 = (lane & 15) >> 2, col4 = (lane & 16) + 4 * (lane & 3);  // tr-read row within the 4-row block / column
+  const int i0 = blockIdx.x * WG2_IB;
+  const int o0 = blockIdx.y * OB;
+  const int u_begin = blockIdx.z * upw;
+  const T* X = (const T*)a.x;
+  const T* DY = (const T*)a.dy;
+  const T zero = from_f<T>(0.f);
+
+  for (int e = tid; e < (WG2_PT - TH * TW) * OBP; e += 256) sdy[TH * TW * OBP + e] = zero;   // rows no tile ever writes
+
+  f32x16 acc[MAXT][OT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int q = 0; q < OT; ++q) acc[t][q] = (f32x16)(0.f);
+
+  int cur_g = -1, ntaps = 0, kw = 1, kh = 1;
+  auto flush = [&]() {
+    if (cur_g < 0) return;
+    float* G = a.G[cur_g];
+    const bool split_k = ntaps < 4;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tap = split_k ? t : wave + 4 * t;
+      if (tap < ntaps) {
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+          const int ci = i0 + r;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int o = o0 + 32 * q + acc_row(reg, lane);
+            if (o < a.Cout && ci < a.Cin) atomicAdd(&G[((long)tap * a.Cout + o) * a.Cin + ci], acc[t][q][reg]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < OT; ++q) acc[t][q] = (f32x16)(0.f);
+    }
+  };
+
+  for (int u = u_begin; u < u_begin + upw && u < units; ++u) {
+    const int tpn = tiles_y * tiles_x;
+    const int n = u / tpn, tyx = u - n * tpn;
+    const int ty0 = (tyx / tiles_x) * TH, tx0 = (tyx % tiles_x) * TW;
+    const int g = find_group(a.seg, a.ngroups, n);
+    if (g != cur_g) {
+      flush();
+      cur_g = g;
+      if (g >= 0) { kh = a.kh[g]; kw = a.kw[g]; ntaps = kh * kw; }
+    }
+    if (g < 0) continue;
+    const int pt = a.pt[g], pl = a.pl[g];
+    const int HWp = TW + kw - 1, HHp = TH + kh - 1;
+    const int rows_valid = min(TH, a.Ho - ty0);
+    const int pv = rows_valid * TW;                          // tile-local pixel index q = ty*TW + tx, q < pv are in the image rows
+    __syncthreads();                                         // previous unit's readers are done
+    {
+      // ---- stage dy tile [q][OBP] (zero outside the image / channel range)
+      const T* dyn = DY + (((long)n * a.Ho + ty0) * a.Wo + tx0) * a.Cout + o0;
+      for (int ty = 0; ty < TH; ++ty) {
+        if (VEC) {
+          for (int e = tid; e < TW * CPP; e += 256) {
+            const int tx = e / CPP, c = (e - tx * CPP) * VW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout)
+              v = *reinterpret_cast<const uint4*>(dyn + ((long)ty * a.Wo + tx) * a.Cout + c);
+            *reinterpret_cast<uint4*>(sdy + (ty * TW + tx) * OBP + c) = v;
+          }
+        } else {
+          for (int e = tid; e < TW * OB; e += 256) {
+            const int tx = e / OB, c = e - tx * OB;
+            T v = zero;
+            if (ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout) v = dyn[((long)ty * a.Wo + tx) * a.Cout + c];
+            sdy[(ty * TW + tx) * OBP + c] = v;
+          }
+        }
+      }
+      // ---- stage x halo [hy][hx][32]
+      const T* xn = X + (long)n * a.H * a.W * a.Cphys;
+      for (int hy = 0; hy < HHp; ++hy) {
+        const int iy = ty0 + hy - pt;
+        const bool rowin = iy >= 0 && iy < a.H;
+        if (VEC) {
+          for (int e = tid; e < HWp * XPP; e += 256) {
+            const int hx = e / XPP, c = (e - hx * XPP) * VW;
+            const int ix = tx0 + hx - pl, ci = i0 + c;
+            T* dst = sx + (hy * HWp + hx) * WG2_IB + c;
+            const bool inb = rowin && ix >= 0 && ix < a.W;
+            if (inb && ci + VW <= a.Cphys) {
+              *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(xn + ((long)iy * a.W + ix) * a.Cphys + ci);
+            } else {
+#pragma unroll
+              for (int j = 0; j < VW; ++j) {
+                T v = zero;
+                if (inb) {
+                  if (ci + j < a.Cphys) v = xn[((long)iy * a.W + ix) * a.Cphys + ci + j];
+                  else if (a.ones && ci + j == a.Cphys) v = from_f<T>(1.f);
+                }
+                dst[j] = v;
+              }
+            }
+          }
+        } else {
+          for (int e = tid; e < HWp * WG2_IB; e += 256) {
+            const int hx = e / WG2_IB, c = e - hx * WG2_IB;
+            const int ix = tx0 + hx - pl, ci = i0 + c;
+            T v = zero;
+            if (rowin && ix >= 0 && ix < a.W) {
+              if (ci < a.Cphys) v = xn[((long)iy * a.W + ix) * a.Cphys + ci];
+              else if (a.ones && ci == a.Cphys) v = from_f<T>(1.f);
+            }
+            sx[(hy * HWp + hx) * WG2_IB + c] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const bool split_k = ntaps < 4;
+    const int nks = (pv + 15) >> 4;
+    for (int ks = (split_k ? wave : 0); ks < nks; ks += (split_k ? 4 : 1)) {
+      Frag8<T> fa[OT];
+      if constexpr (sizeof(T) == 2) {
+        // lane's two pixel rows of the 16-pixel k-step: q = 16 ks + 8 h + q4 (+4)
+        const int qa = ks * 16 + 8 * h + q4, qb = qa + 4;
+#pragma unroll
+        for (int t = 0; t < OT; ++t) load_frag_tr(fa[t], sdy + qa * OBP + 32 * t, sdy + qb * OBP + 32 * t, col4);
+        const int qac = min(qa, pv - 1), qbc = min(qb, pv - 1);           // dy is zero beyond pv; keep x reads in the halo
+        const int tya = qac / TW, tyb = qbc / TW;
+        const T* xa = sx + (tya * HWp + (qac - tya * TW)) * WG2_IB;
+        const T* xb = sx + (tyb * HWp + (qbc - tyb * TW)) * WG2_IB;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int tap = split_k ? t : wave + 4 * t;
+          if (tap < ntaps) {
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const int off = (ky * HWp + kx) * WG2_IB;
+            Frag8<T> fb;
+            load_frag_tr(fb, xa + off, xb + off, col4);
+#pragma unroll
+            for (int q = 0; q < OT; ++q) mma32(acc[t][q], fa[q], fb);
+          }
+        }
+      } else {
+        int qs[8];
+        const int q0 = ks * 16 + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = q0 + j;
+#pragma unroll
+          for (int t = 0; t < OT; ++t) frag_set_raw<T>(fa[t], j, sdy[q * OBP + 32 * t + r]);
+          const int qc = min(q, pv - 1);
+          const int ty = qc / TW, tx = qc - ty * TW;
+          qs[j] = (ty * HWp + tx) * WG2_IB + r;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int tap = split_k ? t : wave + 4 * t;
+          if (tap < ntaps) {
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const int off = (ky * HWp + kx) * WG2_IB;
+            Frag8<T> fb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) frag_set_raw<T>(fb, j, sx[qs[j] + off]);
+#pragma unroll
+            for (int q = 0; q < OT; ++q) mma32(acc[t][q], fa[q], fb);
+          }
+        }
+      }
+    }
+  }
+  flush();
+}
+
 template <typename T, int NB>
 void launch_conv(const ConvArgs& a, bool vec, hipStream_t st) {
   dim3 grid(cdiv((long)a.Ho * a.Wo, 128), a.N, cdiv(a.Cstore, 32 * NB));
@@ -422,6 +638,44 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     const int s = g < ngroups ? g : 0;
     a.G[g] = G[s]; a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
     if (kh[s] * kw[s] > maxtaps) maxtaps = kh[s] * kw[s];
+  }
+  a.tx0 = 0;
+  if (stride == 1) {
+    // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels)
+    const int TW = Wo < WG2_PT ? Wo : WG2_PT;
+    int TH = WG2_PT / TW; if (TH > Ho) TH = Ho; if (TH < 1) TH = 1;
+    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, TW);
+    const long units_l = (long)N * tiles_y * tiles_x;
+    const int units = (int)units_l;
+    int maxkh = 1, maxkw = 1;
+    for (int g = 0; g < ngroups; ++g) { if (kh[g] > maxkh) maxkh = kh[g]; if (kw[g] > maxkw) maxkw = kw[g]; }
+    const int mt = maxtaps < 4 ? maxtaps : (maxtaps + 3) / 4;           // taps per wave
+    const int esz = dtype == HDMOE_BF16 ? 2 : 4;
+    const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
+    const int OB = 32 * OT;
+    const int OBP = (OT == 2 && esz == 2) ? OB + 32 : OB;
+    const size_t lds = (size_t)esz * (WG2_PT * OBP + (TH + maxkh - 1) * (TW + maxkw - 1) * WG2_IB);
+    const int vw = 16 / esz;
+    const bool vec = Cout % vw == 0 && Cphys % vw == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
+    const int ibs = cdiv(Cin, WG2_IB), obs = cdiv(Cout, OB);
+    // every workgroup ends with an atomic flush of its [taps][OB][32] accumulators: keep ~2 workgroups per CU so the
+    // flush traffic (workgroups x weight bytes, at the ~1.3 TB/s float-atomic rate) stays below the MFMA time
+    long upw = ((long)units * ibs * obs + 511) / 512;
+    if (upw < 1) upw = 1;
+    dim3 grid(ibs, obs, cdiv(units, upw));
+    if (lds <= 64 * 1024 && units_l < (1l << 30) && grid.z <= 65535 && mt <= 13) {
+#define WG2_LAUNCH(TT, OTv, MT)                                                                                         \
+  do { if (vec) hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, true>), grid, dim3(256), lds, stream, a, TH, TW, tiles_y, tiles_x, (int)upw, units); \
+       else hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, false>), grid, dim3(256), lds, stream, a, TH, TW, tiles_y, tiles_x, (int)upw, units); } while (0)
+#define WG2_BY_MT(TT, OTv)                                          \
+  if (mt <= 3) WG2_LAUNCH(TT, OTv, 3);                               \
+  else if (mt <= 7) WG2_LAUNCH(TT, OTv, 7);                          \
+  else WG2_LAUNCH(TT, OTv, 13);
+      if (dtype == HDMOE_F32) { if (OT == 2) { WG2_BY_MT(float, 2) } else { WG2_BY_MT(float, 1) } }
+      else if (dtype == HDMOE_BF16) { if (OT == 2) { WG2_BY_MT(bf16, 2) } else { WG2_BY_MT(bf16, 1) } }
+      else return HDMOE_EDTYPE;
+      return hdmoe_launch_status();
+    }
   }
   const int cpl = dtype == HDMOE_BF16 ? 2 : 1;
   a.ob_count = cdiv(Cout, 32 * cpl);
