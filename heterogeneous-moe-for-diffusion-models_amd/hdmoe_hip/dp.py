@@ -34,6 +34,7 @@ class GradBuckets:
             self._seal(cur, n)
         self._pending = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
+        self._next = 0                                             # collectives are issued strictly in bucket order
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         for bi, members in enumerate(self._members):
             for p in members:
@@ -52,8 +53,11 @@ class GradBuckets:
     def _make_hook(self, bi):
         def hook(_p):
             self._pending[bi] += 1
-            if self._pending[bi] == len(self._members[bi]):
-                self._launch(bi)
+            # every rank must issue the same collectives in the same order, but which hooks fire (and when) depends on
+            # the local routing: launch only the contiguous prefix of complete buckets, the rest waits for finish()
+            while self._next < len(self.buckets) and self._pending[self._next] == len(self._members[self._next]):
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def _launch(self, bi):
@@ -66,8 +70,10 @@ class GradBuckets:
 
     def finish(self):
         """Call after backward: reduce buckets whose hooks did not all fire (unused experts), wait for all."""
-        for bi in range(len(self.buckets)):
-            self._launch(bi)
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
+        self._next = 0
         for bi, w in enumerate(self._works):
             if w is not None:
                 w.wait()
