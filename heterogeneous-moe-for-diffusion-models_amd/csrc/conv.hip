@@ -11,6 +11,7 @@
 //   * K is walked tap-major in 16-channel chunks; operands come from global memory as 16-B vectors
 // wgrad:  M = out channels, N = in channels, K = pixels, one tap per wave, fp32 atomics into a
 //   [tap][O][I] slab (contiguous I => full-rate atomic shape, MI355X_MICROARCH "Global float atomics").
+#include <stdlib.h>
 #include "common.h"
 #include "hdmoe.h"
 
@@ -223,6 +224,140 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         float v = a.alpha * acc[b][reg];
         if (res) v += a.beta * to_f(res[(long)pp * a.Cstore + co]);
         y[(long)pp * a.Cstore + co] = from_f<T>(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv forward / dgrad v2 (stride 1): LDS-staged
+// One workgroup = one (sample row, 256-pixel tile, 32*NT output channels).  K is walked in 64-byte channel chunks
+// (32 bf16 / 16 fp32): per chunk the input halo tile [(TH+kh-1) x (TW+kw-1) px][chunk] is staged in LDS ONCE and then
+// read kh*kw times (the reference's im2col re-reads become LDS reads); the weights of one kernel row (kw taps) are
+// staged per ky and shared by the 4 waves.  Each wave owns 64 pixels x 32*NT channels (2 x NT MFMA 32x32 tiles), so
+// every weight fragment is reused twice from registers.  LDS rows are padded 64 -> 80 bytes: the 16 lanes of a
+// ds_read_b128 group then fall on 16 distinct 16-byte slots (5 is coprime to 16) => conflict-free.
+constexpr int CV2_MT = 2;
+
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd2_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap) {
+  constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16, NCH = KC / VW;
+  constexpr int PT = 4 * CV2_MT * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sA = reinterpret_cast<T*>(smem_raw);                    // [halo px][PSE]
+  T* sB = sA + (long)halo_cap * PSE;                         // [kw][32*NT][PSE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int g = find_group(a.seg, a.ngroups, n);
+  if (g < 0) return;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int nbase = blockIdx.z * (32 * NT);
+  const int kh = a.kh[g], kw = a.kw[g], pt = a.pt[g], pl = a.pl[g];
+  const int HWp = TW + kw - 1, HHp = TH + kh - 1;
+  const int npx = TH * TW;                                   // <= PT
+  const T* x = (const T*)a.x + (long)n * a.H * a.W * a.Cphys;
+  const T* w = (const T*)a.w + (long)g * a.wstride;
+  const T zero = from_f<T>(0.f);
+
+  // this lane's pixels (one per M-tile) and their halo base offsets
+  int abase[CV2_MT];
+  bool pval[CV2_MT];
+  int oyv[CV2_MT], oxv[CV2_MT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m) {
+    const int q = wave * (32 * CV2_MT) + m * 32 + r;
+    const int qc = q < npx ? q : npx - 1;
+    const int ty = qc / TW, tx = qc - ty * TW;
+    oyv[m] = ty0 + ty; oxv[m] = tx0 + tx;
+    pval[m] = q < npx && oyv[m] < a.Ho && oxv[m] < a.Wo;
+    abase[m] = (ty * HWp + tx) * PSE + 8 * h;
+  }
+  f32x16 acc[CV2_MT][NT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[m][b] = (f32x16)(0.f);
+
+  for (int c0 = 0; c0 < a.Ipad; c0 += KC) {
+    __syncthreads();                                         // previous chunk's readers done (sA and sB)
+    // ---- stage the halo tile for channels [c0, c0+KC)
+    for (int hy = 0; hy < HHp; ++hy) {
+      const int iy = ty0 + hy - pt;
+      const bool rowin = iy >= 0 && iy < a.H;
+      for (int e = tid; e < HWp * NCH; e += 256) {
+        const int hx = e / NCH, cc = (e - hx * NCH) * VW;
+        const int ix = tx0 + hx - pl, ci = c0 + cc;
+        T* dst = sA + (hy * HWp + hx) * PSE + cc;
+        const bool inb = rowin && ix >= 0 && ix < a.W;
+        const T* src = x + ((long)iy * a.W + ix) * a.Cphys + ci;
+        if (VEC && inb && ci + VW <= a.Cphys) {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VW; ++j) {
+            T v = zero;
+            if (inb) {
+              if (ci + j < a.Cphys) v = src[j];
+              else if (a.ones && ci + j == a.Cphys) v = from_f<T>(1.f);
+            }
+            dst[j] = v;
+          }
+        }
+      }
+    }
+    for (int ky = 0; ky < kh; ++ky) {
+      if (ky) __syncthreads();                               // readers of the previous kernel row's weights done
+      // ---- stage weights of taps (ky, 0..kw-1): [kx][co][KC]
+      for (int e = tid; e < kw * 32 * NT * NCH; e += 256) {
+        const int cc = (e % NCH) * VW; const int row = e / NCH;
+        const int co = row % (32 * NT), kx = row / (32 * NT);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (nbase + co < a.Cout && c0 + cc < a.Ipad)
+          v = *reinterpret_cast<const uint4*>(w + ((long)(ky * kw + kx) * a.Cout + nbase + co) * a.Ipad + c0 + cc);
+        *reinterpret_cast<uint4*>(sB + row * PSE + cc) = v;
+      }
+      __syncthreads();
+      for (int kx = 0; kx < kw; ++kx) {
+        const int aoff = (ky * HWp + kx) * PSE;
+        const T* bt = sB + (kx * 32 * NT + r) * PSE + 8 * h;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+          Frag8<T> fa[CV2_MT], fb[NT];
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m) load8(fa[m], sA + abase[m] + aoff + 16 * s2);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) load8(fb[b], bt + b * 32 * PSE + 16 * s2);
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) mma32(acc[m][b], fa[m], fb[b]);
+        }
+      }
+    }
+  }
+  // ---- epilogue: lanes = channels; register rows = pixels of the M-tile
+  const long img = (long)n * a.Ho * a.Wo;
+  T* y = (T*)a.y;
+  const T* res = (const T*)a.res;
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int co = nbase + 32 * b + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        // pixel of accumulator row `reg`: lanes only know their own pixel, so recompute from the tile-local index
+        const int q = wave * (32 * CV2_MT) + m * 32 + acc_row(reg, lane);
+        if (q < npx && co < a.Cstore) {
+          const int ty = q / TW, tx = q - ty * TW;
+          const int oy = ty0 + ty, ox = tx0 + tx;
+          if (oy < a.Ho && ox < a.Wo) {
+            const long idx = (img + (long)oy * a.Wo + ox) * a.Cstore + co;
+            float v = a.alpha * acc[m][b][reg];
+            if (res) v += a.beta * to_f(res[idx]);
+            y[idx] = from_f<T>(v);
+          }
+        }
       }
     }
   }
@@ -619,9 +754,32 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     const int s = g < ngroups ? g : 0;
     a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
   }
+  if (dtype != HDMOE_F32 && dtype != HDMOE_BF16) return HDMOE_EDTYPE;
+  if (stride == 1 && (long)Ho * Wo >= 64 && !getenv("HDMOE_CONV_V1")) {
+    // ---- v2: LDS-staged 256-pixel tiles
+    const int PT = 4 * CV2_MT * 32;
+    const int TW = Wo < PT ? Wo : PT;
+    int TH = PT / TW; if (TH > Ho) TH = Ho; if (TH < 1) TH = 1;
+    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, TW);
+    int maxkh = 1, maxkw = 1;
+    for (int g = 0; g < ngroups; ++g) { if (kh[g] > maxkh) maxkh = kh[g]; if (kw[g] > maxkw) maxkw = kw[g]; }
+    const int esz = dtype == HDMOE_BF16 ? 2 : 4;
+    const int NT = Cstore <= 32 ? 1 : 2;
+    const int halo_cap = (TH + maxkh - 1) * (TW + maxkw - 1);
+    const size_t lds = (size_t)80 * (halo_cap + maxkw * 32 * NT);
+    const bool vec = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
+    dim3 grid(tiles_y * tiles_x, N, cdiv(Cstore, 32 * NT));
+    if (lds <= 64 * 1024 && grid.x <= 65535 * 32) {
+#define CV2_LAUNCH(TT, NTv)                                                                                                   \
+  do { if (vec) hipLaunchKernelGGL((conv_fwd2_kernel<TT, NTv, true>), grid, dim3(256), lds, stream, a, TH, TW, tiles_x, halo_cap);  \
+       else hipLaunchKernelGGL((conv_fwd2_kernel<TT, NTv, false>), grid, dim3(256), lds, stream, a, TH, TW, tiles_x, halo_cap); } while (0)
+      if (dtype == HDMOE_F32) { if (NT == 1) CV2_LAUNCH(float, 1); else CV2_LAUNCH(float, 2); }
+      else { if (NT == 1) CV2_LAUNCH(bf16, 1); else CV2_LAUNCH(bf16, 2); }
+      return hdmoe_launch_status();
+    }
+  }
   if (dtype == HDMOE_F32) launch_conv_nb<float>(a, Cphys % 4 == 0 && ((uintptr_t)x % 16 == 0), stream);
-  else if (dtype == HDMOE_BF16) launch_conv_nb<bf16>(a, Cphys % 8 == 0 && ((uintptr_t)x % 16 == 0), stream);
-  else return HDMOE_EDTYPE;
+  else launch_conv_nb<bf16>(a, Cphys % 8 == 0 && ((uintptr_t)x % 16 == 0), stream);
   return hdmoe_launch_status();
 }
 
