@@ -102,6 +102,30 @@ DEVI float mp_silu_grad_f(float x) {
   return s * (1.f + x * (1.f - s)) * (1.f / MP_SILU_DIV);
 }
 
+// ---- 16-byte vector access helpers (guide G13: bf16 as 8-wide, fp32 as 4-wide) --------------------------------------
+template <typename T> struct VT;
+template <> struct VT<bf16> { static constexpr int W = 8; };
+template <> struct VT<float> { static constexpr int W = 4; };
+template <typename T> DEVI void vload(float* f, const T* p);
+template <> DEVI void vload<bf16>(float* f, const bf16* p) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+}
+template <> DEVI void vload<float>(float* f, const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <typename T> DEVI void vstore(T* p, const float* f);
+template <> DEVI void vstore<bf16>(bf16* p, const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <> DEVI void vstore<float>(float* p, const float* f) { *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]); }
+static inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; }
+
 static inline int hdmoe_launch_status() {
   return hipGetLastError() == hipSuccess ? HDMOE_OK : HDMOE_ELAUNCH;
 }

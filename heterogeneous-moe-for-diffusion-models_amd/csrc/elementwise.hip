@@ -331,6 +331,164 @@ __global__ void sigmoid_scaling_kernel(float* sv, float* su, float* pair, const 
 }
 
 
+
+// ---------------------------------------------------------------- 16-byte vectorised variants of the hot pointwise ops
+template <typename T>
+__global__ void axpby_vec_kernel(T* out, const T* x, const T* y, float a, float b, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    float f[W], g[W];
+    vload<T>(f, x + v * W);
+    if (y) { vload<T>(g, y + v * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) f[j] = a * f[j] + b * g[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) f[j] = a * f[j];
+    }
+    vstore<T>(out + v * W, f);
+  }
+}
+template <typename T>
+__global__ void mp_silu_fwd_vec_kernel(T* out, const T* x, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    float f[W];
+    vload<T>(f, x + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = mp_silu_f(f[j]);
+    vstore<T>(out + v * W, f);
+  }
+}
+template <typename T>
+__global__ void mp_silu_bwd_vec_kernel(T* dx, const T* dy, const T* x, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    float f[W], g[W];
+    vload<T>(f, x + v * W); vload<T>(g, dy + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = g[j] * mp_silu_grad_f(f[j]);
+    vstore<T>(dx + v * W, f);
+  }
+}
+template <typename T>
+__global__ void film_silu_fwd_vec_kernel(T* out, const T* u, const float* e, long HW, int C, long nv) {
+  constexpr int W = VT<T>::W;
+  const int cv = C / W;
+  GRID_STRIDE(v, nv) {
+    const long row = v / cv; const int c0 = (int)(v - row * cv) * W;
+    const float* ep = e + (row / HW) * C + c0;
+    float f[W];
+    vload<T>(f, u + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = mp_silu_f(f[j] * ep[j]);
+    vstore<T>(out + v * W, f);
+  }
+}
+// block = (pixel chunk, sample); a thread's vectors all carry the same channel chunk (256 % (C/W) == 0): register partials
+template <typename T>
+__global__ __launch_bounds__(256) void film_silu_bwd_vec_kernel(T* du, float* de, const T* da, const T* u, const float* e, long HW, int C, int chunk) {
+  constexpr int W = VT<T>::W;
+  extern __shared__ float sm[];
+  const int s = blockIdx.y, cv = C / W;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+  const long base = (long)s * HW * C;
+  const int c0 = (threadIdx.x % cv) * W;
+  float ev[W], acc[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { ev[j] = e[(long)s * C + c0 + j]; acc[j] = 0.f; }
+  for (long v = p0 * cv + threadIdx.x; v < p1 * cv; v += 256) {
+    float uv[W], g[W];
+    vload<T>(uv, u + base + v * W); vload<T>(g, da + base + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      g[j] *= mp_silu_grad_f(uv[j] * ev[j]);
+      acc[j] += g[j] * uv[j];
+      g[j] *= ev[j];
+    }
+    vstore<T>(du + base + v * W, g);
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) atomicAdd(&sm[c0 + j], acc[j]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&de[(long)s * C + c], sm[c]);
+}
+template <typename T>
+__global__ void scale_rows_fwd_vec_kernel(T* out, const T* x, const float* s, long Lv, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    const float sv = s[v / Lv];
+    float f[W];
+    vload<T>(f, x + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] *= sv;
+    vstore<T>(out + v * W, f);
+  }
+}
+template <typename T>
+__global__ void cat2_fwd_vec_kernel(T* out, const T* a, const T* b, float wa, float wb, int Ca, int Cb, long rows) {
+  constexpr int W = VT<T>::W;
+  const int cva = Ca / W, cv = (Ca + Cb) / W;
+  GRID_STRIDE(v, rows * cv) {
+    const long r = v / cv; const int c = (int)(v - r * cv);
+    float f[W];
+    const bool first = c < cva;
+    vload<T>(f, first ? a + (r * cva + c) * W : b + (r * (cv - cva) + c - cva) * W);
+    const float wgt = first ? wa : wb;
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] *= wgt;
+    vstore<T>(out + v * W, f);
+  }
+}
+template <typename T>
+__global__ void cat2_bwd_vec_kernel(T* da, T* db, const T* dout, float wa, float wb, int Ca, int Cb, long rows) {
+  constexpr int W = VT<T>::W;
+  const int cva = Ca / W, cv = (Ca + Cb) / W;
+  GRID_STRIDE(v, rows * cv) {
+    const long r = v / cv; const int c = (int)(v - r * cv);
+    float f[W];
+    vload<T>(f, dout + v * W);
+    const bool first = c < cva;
+    const float wgt = first ? wa : wb;
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] *= wgt;
+    vstore<T>(first ? da + (r * cva + c) * W : db + (r * (cv - cva) + c - cva) * W, f);
+  }
+}
+// seq_reduce with a fixed channel chunk per thread (256 % (C/W) == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void seq_reduce_vec_kernel(float* out, const T* x, long S, int C, float scale, int chunk) {
+  constexpr int W = VT<T>::W;
+  extern __shared__ float sm[];
+  const int s = blockIdx.y, cv = C / W;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < S) ? p0 + chunk : S;
+  const long base = (long)s * S * C;
+  const int c0 = (threadIdx.x % cv) * W;
+  float acc[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc[j] = 0.f;
+  for (long v = p0 * cv + threadIdx.x; v < p1 * cv; v += 256) {
+    float f[W];
+    vload<T>(f, x + base + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) atomicAdd(&sm[c0 + j], acc[j]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(long)s * C + c], scale * sm[c]);
+}
+template <typename T> static inline bool chunk_fixed_ok(int C) {
+  const int W = VT<T>::W;
+  return C % W == 0 && C / W <= 256 && 256 % (C / W) == 0;
+}
+
 // ---------------------------------------------------------------- adaLN (Router, model_components.py:148-151): x*(1+gamma)+beta, cond = [gamma | beta]
 __global__ void adaln_fwd_kernel(float* out, const float* x, const float* cond, int F, long n) {
   GRID_STRIDE(i, n) {
@@ -408,7 +566,8 @@ __global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, flo
 extern "C" {
 
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x) && al16(y)) L1D(axpby_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, (const T*)y, a, b, n / VT<T>::W);
+                   else L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
 }
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, L1D(affine_kernel<T>, n, (T*)out, (const T*)x, a, c, n))
@@ -425,10 +584,12 @@ int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, hipStrea
   return hdmoe_launch_status();
 }
 int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(mp_silu_fwd_kernel<T>, n, (T*)out, (const T*)x, n))
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x)) L1D(mp_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, n / VT<T>::W);
+                   else L1D(mp_silu_fwd_kernel<T>, n, (T*)out, (const T*)x, n))
 }
 int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(mp_silu_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)x, n))
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(dx) && al16(dy) && al16(x)) L1D(mp_silu_bwd_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, n / VT<T>::W);
+                   else L1D(mp_silu_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)x, n))
 }
 int hdmoe_sigmoid_fwd(void* out, const void* x, float a, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, L1D(sigmoid_fwd_kernel<T>, n, (T*)out, (const T*)x, a, n))
@@ -438,19 +599,23 @@ int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, 
 }
 int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, hipStream_t stream) {
   const long n = (long)N * HW * C;
-  DT_SWITCH(dtype, L1D(film_silu_fwd_kernel<T>, n, (T*)out, (const T*)u, e, HW, C, n))
+  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(u)) L1D(film_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)u, e, HW, C, n / VT<T>::W);
+                   else L1D(film_silu_fwd_kernel<T>, n, (T*)out, (const T*)u, e, HW, C, n))
 }
 int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
                         int dtype, hipStream_t stream) {
   if (N > 65535) return HDMOE_EINVAL;
   const int chunk = 256;
   dim3 grid(cdiv(HW, chunk), N);
-  DT_SWITCH(dtype, hipLaunchKernelGGL(film_silu_bwd_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de,
+  DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(du) && al16(da) && al16(u))
+                     hipLaunchKernelGGL(film_silu_bwd_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de, (const T*)da, (const T*)u, e, HW, C, chunk);
+                   else hipLaunchKernelGGL(film_silu_bwd_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de,
                                       (const T*)da, (const T*)u, e, HW, C, chunk))
 }
 int hdmoe_scale_rows_fwd(void* out, const void* x, const float* s, long rows, long L, int dtype, hipStream_t stream) {
   const long n = rows * L;
-  DT_SWITCH(dtype, L1D(scale_rows_fwd_kernel<T>, n, (T*)out, (const T*)x, s, L, n))
+  DT_SWITCH(dtype, if (L % VT<T>::W == 0 && al16(out) && al16(x)) L1D(scale_rows_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, s, L / VT<T>::W, n / VT<T>::W);
+                   else L1D(scale_rows_fwd_kernel<T>, n, (T*)out, (const T*)x, s, L, n))
 }
 int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, const float* s, long rows, long L,
                          int dtype, hipStream_t stream) {
@@ -462,11 +627,15 @@ int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, con
 }
 int hdmoe_cat2_fwd(void* out, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows, int dtype,
                    hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(cat2_fwd_kernel<T>, rows * (Ca + Cb), (T*)out, (const T*)a, (const T*)b, wa, wb, Ca, Cb, rows))
+  DT_SWITCH(dtype, if (Ca % VT<T>::W == 0 && Cb % VT<T>::W == 0 && al16(out) && al16(a) && al16(b))
+                     L1D(cat2_fwd_vec_kernel<T>, rows * (Ca + Cb) / VT<T>::W, (T*)out, (const T*)a, (const T*)b, wa, wb, Ca, Cb, rows);
+                   else L1D(cat2_fwd_kernel<T>, rows * (Ca + Cb), (T*)out, (const T*)a, (const T*)b, wa, wb, Ca, Cb, rows))
 }
 int hdmoe_cat2_bwd(void* da, void* db, const void* dout, float wa, float wb, int Ca, int Cb, long rows, int dtype,
                    hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(cat2_bwd_kernel<T>, rows * (Ca + Cb), (T*)da, (T*)db, (const T*)dout, wa, wb, Ca, Cb, rows))
+  DT_SWITCH(dtype, if (Ca % VT<T>::W == 0 && Cb % VT<T>::W == 0 && al16(da) && al16(db) && al16(dout))
+                     L1D(cat2_bwd_vec_kernel<T>, rows * (Ca + Cb) / VT<T>::W, (T*)da, (T*)db, (const T*)dout, wa, wb, Ca, Cb, rows);
+                   else L1D(cat2_bwd_kernel<T>, rows * (Ca + Cb), (T*)da, (T*)db, (const T*)dout, wa, wb, Ca, Cb, rows))
 }
 int hdmoe_pool2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, hipStream_t stream) {
   const long n = (long)N * Ho * Wo * C;
@@ -481,7 +650,8 @@ int hdmoe_seq_reduce(float* out, const void* x, int N, long S, int C, float scal
   if (N > 65535 || C > 8192) return HDMOE_EINVAL;
   const int chunk = 64;
   dim3 grid(cdiv(S, chunk), N);
-  DT_SWITCH(dtype, hipLaunchKernelGGL(seq_reduce_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x,
+  DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(x)) hipLaunchKernelGGL(seq_reduce_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x, S, C, scale, chunk);
+                   else hipLaunchKernelGGL(seq_reduce_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x,
                                       S, C, scale, chunk))
 }
 int hdmoe_seq_bcast_add(void* out, const void* x, const float* t, int N, long S, int C, float scale, int dtype,

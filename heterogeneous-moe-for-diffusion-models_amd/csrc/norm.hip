@@ -210,6 +210,332 @@ __global__ void layernorm_bwd_kernel(T* dx, float* dgamma, float* dbeta, const T
   }
 }
 
+
+// =====================================================================================================================
+// Vectorised variants (16-byte accesses, guide G13).  A row of C channels is spread over LPR = pow2 >= C/VW lanes, one
+// 16-byte vector per lane; row reductions are xor-shuffles inside the LPR-lane group (no LDS).
+// =====================================================================================================================
+template <int LPR> DEVI float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void pixelnorm_fwd_vec_kernel(T* xn, T* h, const T* x, int C, long rows) {
+  constexpr int W = VT<T>::W;
+  const int sub = threadIdx.x % LPR;
+  const bool act = sub * W < C;
+  const float rc = rsqrtf((float)C);
+  for (long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPR; r < rows; r += (long)gridDim.x * blockDim.x / LPR) {
+    float v[W];
+    float ss = 0.f;
+    if (act) {
+      vload<T>(v, x + r * C + sub * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) ss += v[j] * v[j];
+    }
+    ss = group_sum<LPR>(ss);
+    const float inv = 1.f / (1e-4f + sqrtf(ss) * rc);
+    if (act) {
+      float o[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) o[j] = v[j] * inv;
+      vstore<T>(xn + r * C + sub * W, o);
+      if (h) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] = mp_silu_f(o[j]);
+        vstore<T>(h + r * C + sub * W, o);
+      }
+    }
+  }
+}
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows) {
+  constexpr int W = VT<T>::W;
+  const int sub = threadIdx.x % LPR;
+  const bool act = sub * W < C;
+  const float rc = rsqrtf((float)C);
+  for (long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPR; r < rows; r += (long)gridDim.x * blockDim.x / LPR) {
+    float v[W], g[W], t[W];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) { v[j] = 0.f; g[j] = 0.f; }
+    if (act) {
+      vload<T>(v, x + r * C + sub * W);
+      if (dxn) vload<T>(g, dxn + r * C + sub * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) ss += v[j] * v[j];
+    }
+    ss = group_sum<LPR>(ss);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.f / (1e-4f + nrm * rc);
+    float dot = 0.f;
+    if (act) {
+      if (dh) {
+        vload<T>(t, dh + r * C + sub * W);
+#pragma unroll
+        for (int j = 0; j < W; ++j) g[j] += t[j] * mp_silu_grad_f(v[j] * inv);
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) dot += g[j] * v[j];
+    }
+    dot = group_sum<LPR>(dot);
+    const float k2 = nrm > 0.f ? dot * rc * inv * inv / nrm : 0.f;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) t[j] = g[j] * inv - k2 * v[j];
+      vstore<T>(dx + r * C + sub * W, t);
+    }
+  }
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(T* y, float* mean, float* rstd, const T* x, const float* gamma,
+                                                               const float* beta, int C, float eps, long rows) {
+  constexpr int W = VT<T>::W;
+  const int sub = threadIdx.x % LPR;
+  const bool act = sub * W < C;
+  float gm[W], bt[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { gm[j] = act ? gamma[sub * W + j] : 0.f; bt[j] = act ? beta[sub * W + j] : 0.f; }
+  for (long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPR; r < rows; r += (long)gridDim.x * blockDim.x / LPR) {
+    float v[W];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = 0.f;
+    if (act) vload<T>(v, x + r * C + sub * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) s += v[j];
+    const float m = group_sum<LPR>(s) / (float)C;
+    float q = 0.f;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) { const float d = v[j] - m; q += d * d; }
+    }
+    const float rs = rsqrtf(group_sum<LPR>(q) / (float)C + eps);
+    if (sub == 0) { mean[r] = m; rstd[r] = rs; }
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) v[j] = (v[j] - m) * rs * gm[j] + bt[j];
+      vstore<T>(y + r * C + sub * W, v);
+    }
+  }
+}
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(T* dx, float* dgamma, float* dbeta, const T* dy, const T* x,
+                                                               const float* gamma, const float* mean, const float* rstd, int C, long rows) {
+  constexpr int W = VT<T>::W;
+  extern __shared__ float sm[];     // [2*C]
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const int sub = threadIdx.x % LPR;
+  const bool act = sub * W < C;
+  float gm[W], dg[W], db[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { gm[j] = act ? gamma[sub * W + j] : 0.f; dg[j] = 0.f; db[j] = 0.f; }
+  const float ic = 1.f / (float)C;
+  for (long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPR; r < rows; r += (long)gridDim.x * blockDim.x / LPR) {
+    float v[W], g[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { v[j] = 0.f; g[j] = 0.f; }
+    const float m = mean[r], rs = rstd[r];
+    float a1 = 0.f, a2 = 0.f;
+    if (act) {
+      vload<T>(v, x + r * C + sub * W);
+      vload<T>(g, dy + r * C + sub * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        v[j] = (v[j] - m) * rs;                      // xhat
+        a1 += g[j] * gm[j]; a2 += g[j] * gm[j] * v[j];
+        dg[j] += g[j] * v[j]; db[j] += g[j];
+      }
+    }
+    a1 = group_sum<LPR>(a1); a2 = group_sum<LPR>(a2);
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) g[j] = rs * (g[j] * gm[j] - ic * (a1 + v[j] * a2));
+      vstore<T>(dx + r * C + sub * W, g);
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) { atomicAdd(&sm[sub * W + j], dg[j]); atomicAdd(&sm[C + sub * W + j], db[j]); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
+}
+
+// ---- GroupNorm, vectorised: one 512-thread block per sample; a thread's vectors all belong to one group and one channel
+// chunk (requires 512 % (C/W) == 0 and (C/G) % W == 0)
+template <typename T>
+__global__ __launch_bounds__(512) void groupnorm_stats_vec_kernel(float* mean, float* rstd, const T* x, long S, int C, int G, float eps) {
+  constexpr int W = VT<T>::W;
+  __shared__ float part[512];
+  __shared__ float red[64];
+  const int n = blockIdx.x, Cg = C / G, cv = C / W;
+  const T* xs = x + (long)n * S * C;
+  const long nv = S * cv;
+  const int mych = (threadIdx.x % cv) * W;
+  const int g = mych / Cg;
+  // group_reduce expects thread t to own group t % G; remap through a per-thread slot instead: reduce over all threads of group g
+  float acc = 0.f;
+  for (long v = threadIdx.x; v < nv; v += blockDim.x) {
+    float f[W];
+    vload<T>(f, xs + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc += f[j];
+  }
+  __syncthreads();
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float s = 0.f;
+    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) s += part[t];
+    red[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const float m = red[g] / (float)(S * Cg);
+  acc = 0.f;
+  for (long v = threadIdx.x; v < nv; v += blockDim.x) {
+    float f[W];
+    vload<T>(f, xs + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) { const float d = f[j] - m; acc += d * d; }
+  }
+  __syncthreads();
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float s = 0.f;
+    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) s += part[t];
+    mean[(long)n * G + threadIdx.x] = red[threadIdx.x] / (float)(S * Cg);
+    rstd[(long)n * G + threadIdx.x] = rsqrtf(s / (float)(S * Cg) + eps);
+  }
+}
+template <typename T>
+__global__ void groupnorm_apply_vec_kernel(T* y, const T* x, const float* gamma, const float* beta, const float* mean,
+                                           const float* rstd, long S, int C, int G, int act, long nvec) {
+  constexpr int W = VT<T>::W;
+  const int Cg = C / G, cv = C / W;
+  GRID_STRIDE(v, nvec) {
+    const long row = v / cv; const int c0 = (int)(v - row * cv) * W;
+    const long sg = (row / S) * G + c0 / Cg;
+    const float m = mean[sg], rs = rstd[sg];
+    float f[W];
+    vload<T>(f, x + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = act_f((f[j] - m) * rs * gamma[c0 + j] + beta[c0 + j], act);
+    vstore<T>(y + v * W, f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const T* dy,
+                                                                     const T* x, const float* gamma, const float* beta, const float* mean,
+                                                                     const float* rstd, long S, int C, int G, int act) {
+  constexpr int W = VT<T>::W;
+  __shared__ float part[512], part2[512];
+  const int n = blockIdx.x, Cg = C / G, cv = C / W;
+  const long base = (long)n * S * C;
+  const long nv = S * cv;
+  const int mych = (threadIdx.x % cv) * W;
+  const int g = mych / Cg;
+  const float m = mean[(long)n * G + g], rs = rstd[(long)n * G + g];
+  float gm[W], bt[W], dg[W], db[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { gm[j] = gamma[mych + j]; bt[j] = beta[mych + j]; dg[j] = 0.f; db[j] = 0.f; }
+  float a1 = 0.f, a2 = 0.f;
+  for (long v = threadIdx.x; v < nv; v += blockDim.x) {
+    float f[W], d[W];
+    vload<T>(f, x + base + v * W);
+    vload<T>(d, dy + base + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const float xh = (f[j] - m) * rs;
+      const float dz = d[j] * act_grad_f(xh * gm[j] + bt[j], act);
+      a1 += dz * gm[j]; a2 += dz * gm[j] * xh;
+      dg[j] += dz * xh; db[j] += dz;
+    }
+  }
+  part[threadIdx.x] = a1; part2[threadIdx.x] = a2;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float u = 0.f, w = 0.f;
+    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) { u += part[t]; w += part2[t]; }
+    s1[(long)n * G + threadIdx.x] = u; s2[(long)n * G + threadIdx.x] = w;
+  }
+  // per-channel partials: threads with the same channel chunk (t % cv) combine through LDS, then one global atomic per channel
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    part[threadIdx.x] = dg[j]; part2[threadIdx.x] = db[j];
+    __syncthreads();
+    if ((int)threadIdx.x < cv) {
+      float u = 0.f, w = 0.f;
+      for (int t = threadIdx.x; t < (int)blockDim.x; t += cv) { u += part[t]; w += part2[t]; }
+      atomicAdd(&dgamma[threadIdx.x * W + j], u); atomicAdd(&dbeta[threadIdx.x * W + j], w);
+    }
+    __syncthreads();
+  }
+}
+template <typename T>
+__global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, const float* gamma, const float* beta, const float* mean,
+                                               const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long nvec) {
+  constexpr int W = VT<T>::W;
+  const int Cg = C / G, cv = C / W;
+  const float invm = 1.f / (float)(S * Cg);
+  GRID_STRIDE(v, nvec) {
+    const long row = v / cv; const int c0 = (int)(v - row * cv) * W;
+    const long sg = (row / S) * G + c0 / Cg;
+    const float m = mean[sg], rs = rstd[sg], u = s1[sg], w = s2[sg];
+    float f[W], d[W];
+    vload<T>(f, x + v * W);
+    vload<T>(d, dy + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const float xh = (f[j] - m) * rs;
+      const float dz = d[j] * act_grad_f(xh * gamma[c0 + j] + beta[c0 + j], act);
+      d[j] = rs * (dz * gamma[c0 + j] - invm * (u + xh * w));
+    }
+    vstore<T>(dx + v * W, d);
+  }
+}
+
+template <typename T> static inline int lpr_for(int C) {
+  const int nv = C / VT<T>::W;
+  int l = 1;
+  while (l < nv) l <<= 1;
+  return l;
+}
+#define LPR_SWITCH(lpr, CALL)                         \
+  switch (lpr) {                                      \
+    case 1: { constexpr int L = 1; CALL; } break;     \
+    case 2: { constexpr int L = 2; CALL; } break;     \
+    case 4: { constexpr int L = 4; CALL; } break;     \
+    case 8: { constexpr int L = 8; CALL; } break;     \
+    case 16: { constexpr int L = 16; CALL; } break;   \
+    case 32: { constexpr int L = 32; CALL; } break;   \
+    default: { constexpr int L = 64; CALL; } break;   \
+  }
+template <typename T> static inline bool row_vec_ok(int C, const void* a, const void* b, const void* c, const void* d) {
+  const int W = VT<T>::W;
+  auto al = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
+  return C % W == 0 && C / W <= 64 && al(a) && al(b) && al(c) && al(d);
+}
+static inline unsigned rows_grid(long rows, int lpr) {
+  long b = (rows * lpr + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+template <typename T> static inline bool gn_vec_ok(int C, int G, const void* a, const void* b, const void* c) {
+  const int W = VT<T>::W;
+  auto al = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
+  if (C % W || (C / G) % W) return false;
+  const int cv = C / W;
+  return cv <= 512 && 512 % cv == 0 && al(a) && al(b) && al(c);
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL)                    \
@@ -220,11 +546,21 @@ __global__ void layernorm_bwd_kernel(T* dx, float* dgamma, float* dbeta, const T
 extern "C" {
 
 int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, if (row_vec_ok<T>(C, xn, h, x, nullptr)) {
+    const int lpr = lpr_for<T>(C);
+    LPR_SWITCH(lpr, hipLaunchKernelGGL((pixelnorm_fwd_vec_kernel<T, L>), dim3(rows_grid(rows, lpr)), dim3(256), 0, stream, (T*)xn, (T*)h, (const T*)x, C, rows))
+    return hdmoe_launch_status();
+  })
   DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_fwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)xn, (T*)h, (const T*)x, C, rows))
   return hdmoe_launch_status();
 }
 int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, int dtype, hipStream_t stream) {
   if (!dxn && !dh) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (row_vec_ok<T>(C, dx, dxn, dh, x)) {
+    const int lpr = lpr_for<T>(C);
+    LPR_SWITCH(lpr, hipLaunchKernelGGL((pixelnorm_bwd_vec_kernel<T, L>), dim3(rows_grid(rows, lpr)), dim3(256), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows))
+    return hdmoe_launch_status();
+  })
   DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_bwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows))
   return hdmoe_launch_status();
 }
@@ -236,6 +572,12 @@ int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const 
                         long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
   if (gn_check(N, C, G)) return HDMOE_EINVAL;
   const long n = (long)N * S * C;
+  DT_SWITCH(dtype, if (gn_vec_ok<T>(C, G, y, x, nullptr)) {
+    const long nvec = n / VT<T>::W;
+    hipLaunchKernelGGL(groupnorm_stats_vec_kernel<T>, dim3(N), dim3(512), 0, stream, mean, rstd, (const T*)x, S, C, G, eps);
+    hipLaunchKernelGGL(groupnorm_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)y, (const T*)x, gamma, beta, mean, rstd, S, C, G, act, nvec);
+    return hdmoe_launch_status();
+  })
   DT_SWITCH(dtype, {
     hipLaunchKernelGGL(groupnorm_stats_kernel<T>, dim3(N), dim3(512), 0, stream, mean, rstd, (const T*)x, S, C, G, eps);
     hipLaunchKernelGGL(groupnorm_apply_kernel<T>, dim3(grid_for(n)), dim3(TPB), 0, stream, (T*)y, (const T*)x, gamma, beta, mean, rstd, S, C, G, act, n);
@@ -249,6 +591,14 @@ int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const 
   if (gn_check(N, C, G)) return HDMOE_EINVAL;
   const long n = (long)N * S * C;
   float* s1 = ws; float* s2 = ws + (long)N * G;
+  DT_SWITCH(dtype, if (gn_vec_ok<T>(C, G, dx, dy, x)) {
+    const long nvec = n / VT<T>::W;
+    hipLaunchKernelGGL(groupnorm_bwd_stats_vec_kernel<T>, dim3(N), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const T*)dy, (const T*)x,
+                       gamma, beta, mean, rstd, S, C, G, act);
+    hipLaunchKernelGGL(groupnorm_bwd_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
+                       gamma, beta, mean, rstd, s1, s2, S, C, G, act, nvec);
+    return hdmoe_launch_status();
+  })
   DT_SWITCH(dtype, {
     hipLaunchKernelGGL(groupnorm_bwd_stats_kernel<T>, dim3(N), dim3(512), 2 * C * sizeof(float), stream, s1, s2, dgamma, dbeta,
                        (const T*)dy, (const T*)x, gamma, beta, mean, rstd, S, C, G, act);
@@ -259,12 +609,24 @@ int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const 
 }
 int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
                         int C, float eps, int dtype, hipStream_t stream) {
+  DT_SWITCH(dtype, if (row_vec_ok<T>(C, y, x, nullptr, nullptr)) {
+    const int lpr = lpr_for<T>(C);
+    LPR_SWITCH(lpr, hipLaunchKernelGGL((layernorm_fwd_vec_kernel<T, L>), dim3(rows_grid(rows, lpr)), dim3(256), 0, stream, (T*)y, mean, rstd, (const T*)x, gamma, beta, C, eps, rows))
+    return hdmoe_launch_status();
+  })
   DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)y, mean, rstd, (const T*)x, gamma, beta, C, eps, rows))
   return hdmoe_launch_status();
 }
 int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, long rows, int C, int dtype, hipStream_t stream) {
   if (C > 4096) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (row_vec_ok<T>(C, dx, dy, x, nullptr)) {
+    const int lpr = lpr_for<T>(C);
+    unsigned gv = rows_grid(rows, lpr); if (gv > 512) gv = 512;
+    LPR_SWITCH(lpr, hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T, L>), dim3(gv), dim3(256), 2 * C * sizeof(float), stream, (T*)dx, dgamma, dbeta,
+                                       (const T*)dy, (const T*)x, gamma, mean, rstd, C, rows))
+    return hdmoe_launch_status();
+  })
   unsigned g = grid_for(rows);
   if (g > 256) g = 256;
   DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(g), dim3(TPB), 2 * C * sizeof(float), stream, (T*)dx, dgamma, dbeta,
