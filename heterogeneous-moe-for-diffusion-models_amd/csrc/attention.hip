@@ -105,6 +105,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dq_kernel(T* dq, float* delta, fl
     }
     __syncthreads();
     if (!act) continue;
+#pragma unroll 8
     for (int j = 0; j < nj; ++j) {
       float s = 0.f, dp = 0.f;
 #pragma unroll
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dkv_kernel(T* dk, T* dv, const T*
     }
     __syncthreads();
     if (!act) continue;
+#pragma unroll 8
     for (int i = 0; i < ni; ++i) {
       float s = 0.f, dp = 0.f;
 #pragma unroll

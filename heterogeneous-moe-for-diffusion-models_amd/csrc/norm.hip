@@ -366,6 +366,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(T* dx, float* dg
   for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
 }
 
+// block reduction per group for the vectorised GroupNorm kernels: thread t carries channel chunk (t % cv); first a strided
+// tree over the 512/cv threads of each chunk, then the cv chunk sums are folded into their groups.  Result in red[g].
+DEVI void vec_group_reduce(float v, int cv, int W, int Cg, int G, float* part, float* red) {
+  __syncthreads();
+  part[threadIdx.x] = v;
+  __syncthreads();
+  for (int stride = (int)blockDim.x >> 1; stride >= cv; stride >>= 1) {
+    if ((int)threadIdx.x < stride) part[threadIdx.x] += part[threadIdx.x + stride];
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < G) {
+    float s = 0.f;
+    const int per = Cg / W;                                  // chunks per group
+    for (int c = threadIdx.x * per; c < (threadIdx.x + 1) * per; ++c) s += part[c];
+    red[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
 // ---- GroupNorm, vectorised: one 512-thread block per sample; a thread's vectors all belong to one group and one channel
 // chunk (requires 512 % (C/W) == 0 and (C/G) % W == 0)
 template <typename T>
@@ -386,15 +405,7 @@ __global__ __launch_bounds__(512) void groupnorm_stats_vec_kernel(float* mean, f
 #pragma unroll
     for (int j = 0; j < W; ++j) acc += f[j];
   }
-  __syncthreads();
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  if ((int)threadIdx.x < G) {
-    float s = 0.f;
-    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) s += part[t];
-    red[threadIdx.x] = s;
-  }
-  __syncthreads();
+  vec_group_reduce(acc, cv, W, Cg, G, part, red);
   const float m = red[g] / (float)(S * Cg);
   acc = 0.f;
   for (long v = threadIdx.x; v < nv; v += blockDim.x) {
@@ -403,14 +414,13 @@ __global__ __launch_bounds__(512) void groupnorm_stats_vec_kernel(float* mean, f
 #pragma unroll
     for (int j = 0; j < W; ++j) { const float d = f[j] - m; acc += d * d; }
   }
-  __syncthreads();
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  if ((int)threadIdx.x < G) {
-    float s = 0.f;
-    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) s += part[t];
-    mean[(long)n * G + threadIdx.x] = red[threadIdx.x] / (float)(S * Cg);
-    rstd[(long)n * G + threadIdx.x] = rsqrtf(s / (float)(S * Cg) + eps);
+  const float mkeep = m;
+  vec_group_reduce(acc, cv, W, Cg, G, part, red);
+  if ((int)threadIdx.x % cv == 0 || true) {
+    if ((int)threadIdx.x < cv && (mych % Cg) == 0) {        // first channel chunk of each group writes its statistics
+      mean[(long)n * G + g] = mkeep;
+      rstd[(long)n * G + g] = rsqrtf(red[g] / (float)(S * Cg) + eps);
+    }
   }
 }
 template <typename T>
@@ -457,25 +467,22 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
       dg[j] += dz * xh; db[j] += dz;
     }
   }
-  part[threadIdx.x] = a1; part2[threadIdx.x] = a2;
-  __syncthreads();
-  if ((int)threadIdx.x < G) {
-    float u = 0.f, w = 0.f;
-    for (int t = 0; t < (int)blockDim.x; ++t) if (((t % cv) * W) / Cg == (int)threadIdx.x) { u += part[t]; w += part2[t]; }
-    s1[(long)n * G + threadIdx.x] = u; s2[(long)n * G + threadIdx.x] = w;
-  }
-  // per-channel partials: threads with the same channel chunk (t % cv) combine through LDS, then one global atomic per channel
-  __syncthreads();
+  __shared__ float red[64];
+  vec_group_reduce(a1, cv, W, Cg, G, part, red);
+  if ((int)threadIdx.x < G) s1[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  vec_group_reduce(a2, cv, W, Cg, G, part, red);
+  if ((int)threadIdx.x < G) s2[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  // per-channel partials: strided tree over the threads that share a channel chunk, then one global atomic per channel
 #pragma unroll
   for (int j = 0; j < W; ++j) {
+    __syncthreads();
     part[threadIdx.x] = dg[j]; part2[threadIdx.x] = db[j];
     __syncthreads();
-    if ((int)threadIdx.x < cv) {
-      float u = 0.f, w = 0.f;
-      for (int t = threadIdx.x; t < (int)blockDim.x; t += cv) { u += part[t]; w += part2[t]; }
-      atomicAdd(&dgamma[threadIdx.x * W + j], u); atomicAdd(&dbeta[threadIdx.x * W + j], w);
+    for (int stride = (int)blockDim.x >> 1; stride >= cv; stride >>= 1) {
+      if ((int)threadIdx.x < stride) { part[threadIdx.x] += part[threadIdx.x + stride]; part2[threadIdx.x] += part2[threadIdx.x + stride]; }
+      __syncthreads();
     }
-    __syncthreads();
+    if ((int)threadIdx.x < cv) { atomicAdd(&dgamma[threadIdx.x * W + j], part[threadIdx.x]); atomicAdd(&dbeta[threadIdx.x * W + j], part2[threadIdx.x]); }
   }
 }
 template <typename T>

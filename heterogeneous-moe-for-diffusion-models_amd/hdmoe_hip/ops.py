@@ -105,10 +105,15 @@ class _MPConvFn(torch.autograd.Function):
             raise RuntimeError(f"MP_Conv: input has {Cphys} channels, weight expects {I}")
         Ho, Wo = Hos.pop(), W
         Ipad = (I + 15) // 16 * 16
-        wstride = max(a * b for a, b in zip(khs, kws)) * O * Ipad
+        Opad = (O + 15) // 16 * 16
+        taps = max(a * b for a, b in zip(khs, kws))
+        wstride, wdstride = taps * O * Ipad, taps * I * Opad
         wf = torch.empty(G * wstride, dtype=x.dtype, device=x.device)
-        call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, 16, wf, wstride, None, 0,
-             1 if normalize else 0, 1 if training else 0, 0, _dt(x))
+        # the flipped dgrad image is produced by the same prep launch when the input needs a gradient
+        wd = torch.empty(G * wdstride, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+        call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
+             1 if normalize else 0, 1 if training else 0, 1, _dt(x))
+        ctx.wd = wd
         y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
         _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
                seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
@@ -130,14 +135,9 @@ class _MPConvFn(torch.autograd.Function):
         need_gain = gains is not None and any(nig[4 + G + g] for g in range(G))
         need_w = any(nig[4 + g] for g in range(G)) or need_gain
         if nig[0]:
-            Ipad = (I + 15) // 16 * 16
             Opad = (O + 15) // 16 * 16
-            taps = max(a * b for a, b in zip(khs, kws))
-            wstride, wdstride = taps * O * Ipad, taps * I * Opad
-            wf = torch.empty(G * wstride, dtype=dt, device=x.device)
-            wd = torch.empty(G * wdstride, dtype=dt, device=x.device)
-            call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
-                 1 if normalize else 0, 0, 1, _dt(x))
+            wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
+            wd = ctx.wd
             dx = torch.empty_like(x)
             pt_d = [kh - 1 - p for kh, p in zip(khs, pts)]
             pl_d = [kw - 1 - p for kw, p in zip(kws, pts)]
@@ -150,7 +150,12 @@ class _MPConvFn(torch.autograd.Function):
         dws: List[Optional[Tensor]] = [None] * G
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w:
-            Gs = [torch.zeros((khs[g] * kws[g], O, I), dtype=torch.float32, device=x.device) for g in range(G)]
+            sizes = [khs[g] * kws[g] * O * I for g in range(G)]
+            Gflat = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)           # one memset for all groups
+            Gs, off = [], 0
+            for g in range(G):
+                Gs.append(Gflat[off:off + sizes[g]])
+                off += sizes[g]
             _timed("conv_wgrad", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W,
                    Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
             dws = [torch.empty_like(w) for w in weights]
