@@ -497,8 +497,13 @@ DEVI void load_frag_tr(Frag8<bf16>& f, const bf16* rowa, const bf16* rowb, int c
   f.v = __builtin_bit_cast(bf16x8, v);
 }
 
+struct Wg2Geom {                      // launch geometry of one kernel-size class
+  int TH, TW, tw_shift, tiles_y, tiles_x, upw, chunks, ngr;
+  int groups[HDMOE_MAX_GROUPS];       // the groups (experts) of this class
+};
+
 template <typename T, int OT, int MAXT, bool VEC>
-__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, int TW, int tiles_y, int tiles_x, int upw, int units) {
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, Wg2Geom gm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int OB = 32 * OT;
   constexpr int OBP = (OT == 2 && sizeof(T) == 2) ? OB + 32 : OB;      // bank-conflict-free row stride for the tr reads
@@ -512,121 +517,144 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, i
   const int q4 = (lane & 15) >> 2, col4 = (lane & 16) + 4 * (lane & 3);  // tr-read row within the 4-row block / column
   const int i0 = blockIdx.x * WG2_IB;
   const int o0 = blockIdx.y * OB;
-  const int u_begin = blockIdx.z * upw;
+  const int TH = gm.TH, TW = gm.TW, tw_shift = gm.tw_shift;
+  // ---- this workgroup: one chunk of the units of ONE group (expert); the group's row range comes from the device-side plan
+  const int g = gm.groups[blockIdx.z / gm.chunks];
+  const int chunk = blockIdx.z % gm.chunks;
+  const int tpn = gm.tiles_y * gm.tiles_x;
+  const int row0 = a.seg ? a.seg[g] : 0, row1 = a.seg ? a.seg[g + 1] : a.N;
+  const int u0 = row0 * tpn + chunk * gm.upw;
+  const int u1 = min(row1 * tpn, u0 + gm.upw);
+  if (u0 >= u1) return;
+  const int kh = a.kh[g], kw = a.kw[g], pt = a.pt[g], pl = a.pl[g];
+  const int ntaps = kh * kw;
+  const bool split_k = ntaps < 4;
+  const int HWp = TW + kw - 1, HHp = TH + kh - 1;
+  const int nh = HHp * HWp * XPP;
+  const int magic_hw = (1 << 20) / HWp + 1, magic_tpn = (1 << 20) / tpn + 1, magic_tx = (1 << 20) / gm.tiles_x + 1;
   const T* X = (const T*)a.x;
   const T* DY = (const T*)a.dy;
   const T zero = from_f<T>(0.f);
+  // integer division is ~35 VALU instructions on CDNA: tile widths are powers of two in every shipped config (shift path),
+  // the other divisors get a 20-bit reciprocal (exact for the small indices used here)
+  auto div_tw = [&](int q) { return tw_shift >= 0 ? (q >> tw_shift) : q / TW; };
+  auto fast_div = [](int q, int magic) { return (int)(((unsigned)q * (unsigned)magic) >> 20); };
 
   for (int e = tid; e < (WG2_PT - TH * TW) * OBP; e += 256) sdy[TH * TW * OBP + e] = zero;   // rows no tile ever writes
 
+  int toff[MAXT];                                             // LDS offset of this wave's taps inside the halo tile
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = split_k ? t : wave + 4 * t;
+    const int ky = tap / kw, kx = tap - ky * kw;
+    toff[t] = (ky * HWp + kx) * WG2_IB;
+  }
   f32x16 acc[MAXT][OT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
     for (int q = 0; q < OT; ++q) acc[t][q] = (f32x16)(0.f);
 
-  int cur_g = -1, ntaps = 0, kw = 1, kh = 1;
-  auto flush = [&]() {
-    if (cur_g < 0) return;
-    float* G = a.G[cur_g];
-    const bool split_k = ntaps < 4;
+  constexpr int NDY = (WG2_PT * CPP + 255) / 256;
+  constexpr int NX = sizeof(T) == 2 ? 6 : 8;                  // halo chunks per thread held in registers (host checks the cap)
+  uint4 rdy[VEC ? NDY : 1], rx[VEC ? NX : 1];
+  // unit -> (sample, tile origin); large unit indices (flattened linear layers) take the exact division
+  auto unit_origin = [&](int u, int& n, int& ty0, int& tx0) {
+    n = u < (1 << 12) ? fast_div(u, magic_tpn) : u / tpn;
+    const int tyx = u - n * tpn;
+    const int tyi = tyx < (1 << 12) ? fast_div(tyx, magic_tx) : tyx / gm.tiles_x;
+    ty0 = tyi * TH; tx0 = (tyx - tyi * gm.tiles_x) * TW;
+  };
+  auto prefetch = [&](int u) {                                 // global -> registers (VEC path)
+    int n, ty0, tx0;
+    unit_origin(u, n, ty0, tx0);
+    const int rows_valid = min(TH, a.Ho - ty0);
+    const T* dyn = DY + (((long)n * a.Ho + ty0) * a.Wo + tx0) * a.Cout + o0;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int tap = split_k ? t : wave + 4 * t;
-      if (tap < ntaps) {
+    for (int k = 0; k < NDY; ++k) {
+      const int idx = tid + k * 256;
+      const int pq = idx / CPP, c = (idx - pq * CPP) * VW;
+      const int ty = div_tw(pq), tx = pq - ty * TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pq < TH * TW && ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout)
+        v = *reinterpret_cast<const uint4*>(dyn + ((long)ty * a.Wo + tx) * a.Cout + c);
+      rdy[k] = v;
+    }
+    const T* xn = X + (long)n * a.H * a.W * a.Cphys;
 #pragma unroll
-        for (int q = 0; q < OT; ++q) {
-          const int ci = i0 + r;
+    for (int k = 0; k < NX; ++k) {
+      const int idx = tid + k * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < nh) {
+        const int px = idx / XPP, c = (idx - px * XPP) * VW;
+        const int hy = fast_div(px, magic_hw), hx = px - hy * HWp;
+        const int iy = ty0 + hy - pt, ix = tx0 + hx - pl, ci = i0 + c;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          if (ci + VW <= a.Cphys) v = *reinterpret_cast<const uint4*>(xn + ((long)iy * a.W + ix) * a.Cphys + ci);
+          else {
+            T tmp[VW];
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int o = o0 + 32 * q + acc_row(reg, lane);
-            if (o < a.Cout && ci < a.Cin) atomicAdd(&G[((long)tap * a.Cout + o) * a.Cin + ci], acc[t][q][reg]);
+            for (int j = 0; j < VW; ++j) {
+              T e = zero;
+              if (ci + j < a.Cphys) e = xn[((long)iy * a.W + ix) * a.Cphys + ci + j];
+              else if (a.ones && ci + j == a.Cphys) e = from_f<T>(1.f);
+              tmp[j] = e;
+            }
+            v = *reinterpret_cast<const uint4*>(tmp);
           }
         }
       }
-#pragma unroll
-      for (int q = 0; q < OT; ++q) acc[t][q] = (f32x16)(0.f);
+      rx[k] = v;
     }
   };
 
-  for (int u = u_begin; u < u_begin + upw && u < units; ++u) {
-    const int tpn = tiles_y * tiles_x;
-    const int n = u / tpn, tyx = u - n * tpn;
-    const int ty0 = (tyx / tiles_x) * TH, tx0 = (tyx % tiles_x) * TW;
-    const int g = find_group(a.seg, a.ngroups, n);
-    if (g != cur_g) {
-      flush();
-      cur_g = g;
-      if (g >= 0) { kh = a.kh[g]; kw = a.kw[g]; ntaps = kh * kw; }
-    }
-    if (g < 0) continue;
-    const int pt = a.pt[g], pl = a.pl[g];
-    const int HWp = TW + kw - 1, HHp = TH + kh - 1;
-    const int rows_valid = min(TH, a.Ho - ty0);
-    const int pv = rows_valid * TW;                          // tile-local pixel index q = ty*TW + tx, q < pv are in the image rows
+  if (VEC) prefetch(u0);
+  for (int u = u0; u < u1; ++u) {
+    int n, ty0, tx0;
+    unit_origin(u, n, ty0, tx0);
+    const int pv = min(TH, a.Ho - ty0) * TW;                 // tile-local pixels q = ty*TW + tx below pv lie in image rows
     __syncthreads();                                         // previous unit's readers are done
-    {
-      // ---- stage dy tile [q][OBP] (zero outside the image / channel range)
+    if (VEC) {
+#pragma unroll
+      for (int k = 0; k < NDY; ++k) {
+        const int idx = tid + k * 256;
+        const int pq = idx / CPP, c = (idx - pq * CPP) * VW;
+        if (pq < TH * TW) *reinterpret_cast<uint4*>(sdy + pq * OBP + c) = rdy[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int idx = tid + k * 256;
+        if (idx < nh) *reinterpret_cast<uint4*>(sx + (idx / XPP) * WG2_IB + (idx % XPP) * VW) = rx[k];
+      }
+    } else {
+      const int rows_valid = min(TH, a.Ho - ty0);
       const T* dyn = DY + (((long)n * a.Ho + ty0) * a.Wo + tx0) * a.Cout + o0;
       for (int ty = 0; ty < TH; ++ty) {
-        if (VEC) {
-          for (int e = tid; e < TW * CPP; e += 256) {
-            const int tx = e / CPP, c = (e - tx * CPP) * VW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout)
-              v = *reinterpret_cast<const uint4*>(dyn + ((long)ty * a.Wo + tx) * a.Cout + c);
-            *reinterpret_cast<uint4*>(sdy + (ty * TW + tx) * OBP + c) = v;
-          }
-        } else {
-          for (int e = tid; e < TW * OB; e += 256) {
-            const int tx = e / OB, c = e - tx * OB;
-            T v = zero;
-            if (ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout) v = dyn[((long)ty * a.Wo + tx) * a.Cout + c];
-            sdy[(ty * TW + tx) * OBP + c] = v;
-          }
+        for (int e = tid; e < TW * OB; e += 256) {
+          const int tx = e / OB, c = e - tx * OB;
+          T v = zero;
+          if (ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout) v = dyn[((long)ty * a.Wo + tx) * a.Cout + c];
+          sdy[(ty * TW + tx) * OBP + c] = v;
         }
       }
-      // ---- stage x halo [hy][hx][32]
       const T* xn = X + (long)n * a.H * a.W * a.Cphys;
       for (int hy = 0; hy < HHp; ++hy) {
         const int iy = ty0 + hy - pt;
         const bool rowin = iy >= 0 && iy < a.H;
-        if (VEC) {
-          for (int e = tid; e < HWp * XPP; e += 256) {
-            const int hx = e / XPP, c = (e - hx * XPP) * VW;
-            const int ix = tx0 + hx - pl, ci = i0 + c;
-            T* dst = sx + (hy * HWp + hx) * WG2_IB + c;
-            const bool inb = rowin && ix >= 0 && ix < a.W;
-            if (inb && ci + VW <= a.Cphys) {
-              *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(xn + ((long)iy * a.W + ix) * a.Cphys + ci);
-            } else {
-#pragma unroll
-              for (int j = 0; j < VW; ++j) {
-                T v = zero;
-                if (inb) {
-                  if (ci + j < a.Cphys) v = xn[((long)iy * a.W + ix) * a.Cphys + ci + j];
-                  else if (a.ones && ci + j == a.Cphys) v = from_f<T>(1.f);
-                }
-                dst[j] = v;
-              }
-            }
+        for (int e = tid; e < HWp * WG2_IB; e += 256) {
+          const int hx = e / WG2_IB, c = e - hx * WG2_IB;
+          const int ix = tx0 + hx - pl, ci = i0 + c;
+          T v = zero;
+          if (rowin && ix >= 0 && ix < a.W) {
+            if (ci < a.Cphys) v = xn[((long)iy * a.W + ix) * a.Cphys + ci];
+            else if (a.ones && ci == a.Cphys) v = from_f<T>(1.f);
           }
-        } else {
-          for (int e = tid; e < HWp * WG2_IB; e += 256) {
-            const int hx = e / WG2_IB, c = e - hx * WG2_IB;
-            const int ix = tx0 + hx - pl, ci = i0 + c;
-            T v = zero;
-            if (rowin && ix >= 0 && ix < a.W) {
-              if (ci < a.Cphys) v = xn[((long)iy * a.W + ix) * a.Cphys + ci];
-              else if (a.ones && ci == a.Cphys) v = from_f<T>(1.f);
-            }
-            sx[(hy * HWp + hx) * WG2_IB + c] = v;
-          }
+          sx[(hy * HWp + hx) * WG2_IB + c] = v;
         }
       }
     }
     __syncthreads();
-    const bool split_k = ntaps < 4;
+    if (VEC && u + 1 < u1) prefetch(u + 1);                  // next unit's loads fly while this unit computes
     const int nks = (pv + 15) >> 4;
     for (int ks = (split_k ? wave : 0); ks < nks; ks += (split_k ? 4 : 1)) {
       Frag8<T> fa[OT];
@@ -636,17 +664,15 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, i
 #pragma unroll
         for (int t = 0; t < OT; ++t) load_frag_tr(fa[t], sdy + qa * OBP + 32 * t, sdy + qb * OBP + 32 * t, col4);
         const int qac = min(qa, pv - 1), qbc = min(qb, pv - 1);           // dy is zero beyond pv; keep x reads in the halo
-        const int tya = qac / TW, tyb = qbc / TW;
+        const int tya = div_tw(qac), tyb = div_tw(qbc);
         const T* xa = sx + (tya * HWp + (qac - tya * TW)) * WG2_IB;
         const T* xb = sx + (tyb * HWp + (qbc - tyb * TW)) * WG2_IB;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
           const int tap = split_k ? t : wave + 4 * t;
           if (tap < ntaps) {
-            const int ky = tap / kw, kx = tap - ky * kw;
-            const int off = (ky * HWp + kx) * WG2_IB;
             Frag8<T> fb;
-            load_frag_tr(fb, xa + off, xb + off, col4);
+            load_frag_tr(fb, xa + toff[t], xb + toff[t], col4);
 #pragma unroll
             for (int q = 0; q < OT; ++q) mma32(acc[t][q], fa[q], fb);
           }
@@ -660,18 +686,16 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, i
 #pragma unroll
           for (int t = 0; t < OT; ++t) frag_set_raw<T>(fa[t], j, sdy[q * OBP + 32 * t + r]);
           const int qc = min(q, pv - 1);
-          const int ty = qc / TW, tx = qc - ty * TW;
+          const int ty = div_tw(qc), tx = qc - ty * TW;
           qs[j] = (ty * HWp + tx) * WG2_IB + r;
         }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
           const int tap = split_k ? t : wave + 4 * t;
           if (tap < ntaps) {
-            const int ky = tap / kw, kx = tap - ky * kw;
-            const int off = (ky * HWp + kx) * WG2_IB;
             Frag8<T> fb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) frag_set_raw<T>(fb, j, sx[qs[j] + off]);
+            for (int j = 0; j < 8; ++j) frag_set_raw<T>(fb, j, sx[qs[j] + toff[t]]);
 #pragma unroll
             for (int q = 0; q < OT; ++q) mma32(acc[t][q], fa[q], fb);
           }
@@ -679,7 +703,23 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, int TH, i
       }
     }
   }
-  flush();
+  // ---- one coalesced fp32 atomic flush: lanes = 32 consecutive input channels (128-byte runs)
+  float* G = a.G[g];
+  const int ci = i0 + r;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = split_k ? t : wave + 4 * t;
+    if (tap < ntaps) {
+#pragma unroll
+      for (int q = 0; q < OT; ++q) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int o = o0 + 32 * q + acc_row(reg, lane);
+          if (o < a.Cout && ci < a.Cin) atomicAdd(&G[((long)tap * a.Cout + o) * a.Cin + ci], acc[t][q][reg]);
+        }
+      }
+    }
+  }
 }
 
 template <typename T, int NB>
@@ -799,39 +839,61 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
   }
   a.tx0 = 0;
   if (stride == 1) {
-    // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels)
-    const int TW = Wo < WG2_PT ? Wo : WG2_PT;
-    int TH = WG2_PT / TW; if (TH > Ho) TH = Ho; if (TH < 1) TH = 1;
-    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, TW);
-    const long units_l = (long)N * tiles_y * tiles_x;
-    const int units = (int)units_l;
-    int maxkh = 1, maxkw = 1;
-    for (int g = 0; g < ngroups; ++g) { if (kh[g] > maxkh) maxkh = kh[g]; if (kw[g] > maxkw) maxkw = kw[g]; }
-    const int mt = maxtaps < 4 ? maxtaps : (maxtaps + 3) / 4;           // taps per wave
+    // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels); one launch per kernel-size class so the
+    //      per-wave accumulator count (MAXT) matches the class (3x3 -> 3, 5x5 -> 7, 7x7 -> 13)
+    Wg2Geom gm;
+    gm.TW = Wo < WG2_PT ? Wo : WG2_PT;
+    gm.TH = WG2_PT / gm.TW; if (gm.TH > Ho) gm.TH = Ho; if (gm.TH < 1) gm.TH = 1;
+    gm.tw_shift = -1;
+    for (int sft = 0; sft < 8; ++sft) if ((1 << sft) == gm.TW) gm.tw_shift = sft;
+    gm.tiles_y = cdiv(Ho, gm.TH); gm.tiles_x = cdiv(Wo, gm.TW);
+    const long units_l = (long)N * gm.tiles_y * gm.tiles_x;
     const int esz = dtype == HDMOE_BF16 ? 2 : 4;
-    const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
-    const int OB = 32 * OT;
-    const int OBP = (OT == 2 && esz == 2) ? OB + 32 : OB;
-    const size_t lds = (size_t)esz * (WG2_PT * OBP + (TH + maxkh - 1) * (TW + maxkw - 1) * WG2_IB);
     const int vw = 16 / esz;
-    const bool vec = Cout % vw == 0 && Cphys % vw == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
-    const int ibs = cdiv(Cin, WG2_IB), obs = cdiv(Cout, OB);
-    // every workgroup ends with an atomic flush of its [taps][OB][32] accumulators: keep ~2 workgroups per CU so the
-    // flush traffic (workgroups x weight bytes, at the ~1.3 TB/s float-atomic rate) stays below the MFMA time
-    long upw = ((long)units * ibs * obs + 511) / 512;
-    if (upw < 1) upw = 1;
-    dim3 grid(ibs, obs, cdiv(units, upw));
-    if (lds <= 64 * 1024 && units_l < (1l << 30) && grid.z <= 65535 && mt <= 13) {
-#define WG2_LAUNCH(TT, OTv, MT)                                                                                         \
-  do { if (vec) hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, true>), grid, dim3(256), lds, stream, a, TH, TW, tiles_y, tiles_x, (int)upw, units); \
-       else hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, false>), grid, dim3(256), lds, stream, a, TH, TW, tiles_y, tiles_x, (int)upw, units); } while (0)
+    bool done[HDMOE_MAX_GROUPS] = {false};
+    bool ok = units_l < (1l << 30) && (dtype == HDMOE_F32 || dtype == HDMOE_BF16);
+    // feasibility of every class first (fall back to v1 as a whole otherwise)
+    for (int g = 0; g < ngroups && ok; ++g) {
+      const int taps = kh[g] * kw[g];
+      const int mt = taps < 4 ? taps : (taps + 3) / 4;
+      const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
+      const int OBP = (OT == 2 && esz == 2) ? 96 : 32 * OT;
+      const size_t lds = (size_t)esz * (WG2_PT * OBP + (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1) * WG2_IB);
+      if (lds > 64 * 1024 || mt > 13) ok = false;
+    }
+    if (ok) {
+      for (int g = 0; g < ngroups; ++g) {
+        if (done[g]) continue;
+        gm.ngr = 0;
+        for (int g2 = g; g2 < ngroups; ++g2)
+          if (!done[g2] && kh[g2] == kh[g] && kw[g2] == kw[g]) { gm.groups[gm.ngr++] = g2; done[g2] = true; }
+        const int taps = kh[g] * kw[g];
+        const int mt = taps < 4 ? taps : (taps + 3) / 4;
+        const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
+        const int OB = 32 * OT, OBP = (OT == 2 && esz == 2) ? OB + 32 : OB;
+        const int halo = (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1);
+        const size_t lds = (size_t)esz * (WG2_PT * OBP + halo * WG2_IB);
+        const int nx_cap = (esz == 2 ? 6 : 8) * 256;                    // register-prefetch capacity (16-B halo chunks)
+        const bool vec = Cout % vw == 0 && Cphys % vw == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 &&
+                         halo * (WG2_IB / vw) <= nx_cap;
+        const int ibs = cdiv(Cin, WG2_IB), obs = cdiv(Cout, OB);
+        // every workgroup ends with an atomic flush of its [taps][OB][32] accumulators; the flush traffic is
+        // (pixel partitions) x (weight bytes) at ~1.3 TB/s, so keep the partition count near 256 / (ibs * obs) per launch
+        long parts = 384 / ((long)ibs * obs); if (parts < 8) parts = 8;
+        long upw = (units_l + parts - 1) / parts; if (upw < 1) upw = 1;
+        gm.upw = (int)upw;
+        gm.chunks = (int)((units_l + upw - 1) / upw);
+        dim3 grid(ibs, obs, gm.chunks * gm.ngr);
+#define WG2_LAUNCH(TT, OTv, MT)                                                                                           \
+  do { if (vec) hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, true>), grid, dim3(256), lds, stream, a, gm);          \
+       else hipLaunchKernelGGL((conv_wgrad2_kernel<TT, OTv, MT, false>), grid, dim3(256), lds, stream, a, gm); } while (0)
 #define WG2_BY_MT(TT, OTv)                                          \
   if (mt <= 3) WG2_LAUNCH(TT, OTv, 3);                               \
   else if (mt <= 7) WG2_LAUNCH(TT, OTv, 7);                          \
   else WG2_LAUNCH(TT, OTv, 13);
-      if (dtype == HDMOE_F32) { if (OT == 2) { WG2_BY_MT(float, 2) } else { WG2_BY_MT(float, 1) } }
-      else if (dtype == HDMOE_BF16) { if (OT == 2) { WG2_BY_MT(bf16, 2) } else { WG2_BY_MT(bf16, 1) } }
-      else return HDMOE_EDTYPE;
+        if (dtype == HDMOE_F32) { if (OT == 2) { WG2_BY_MT(float, 2) } else { WG2_BY_MT(float, 1) } }
+        else { if (OT == 2) { WG2_BY_MT(bf16, 2) } else { WG2_BY_MT(bf16, 1) } }
+      }
       return hdmoe_launch_status();
     }
   }
