@@ -11,6 +11,7 @@ normalisation all run).  One step = forward + fused EDM_LOSS + backward (+ gradi
 Prints ONE JSON line on rank 0.  Only the `cpu_baseline` leg touches oracle/ (the CPU restatement, timed as a baseline).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -80,15 +81,26 @@ def roofline_leg(step_fn, n_steps):
         step_fn()
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    # An event pair also spans any host-side gap while the stream is idle (tiny launches are host-latency bound), so a
+    # launch's duration is taken as min(measured, median of its shape): robust against host hiccups, exact for GPU-bound launches.
     agg = {}
+    shapes = {}
+    per_shape = {}
     for kind, info, s, e in rec:
-        tname = "float" if info["dtype"] == "float32" else "__bf16"
-        name = f"conv_fwd_kernel<{tname}, {info['nb']}, {'true' if info['vec'] else 'false'}>" if kind == "conv_fwd" \
-            else f"conv_wgrad_kernel<{tname}>"
-        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, n=0, dtype=info["dtype"]))
-        a["ms"] += s.elapsed_time(e)
-        a["flops"] += conv_flops(info)
-        a["n"] += 1
+        name = info["fwd_name"] if kind == "conv_fwd" else info["wgrad_name"]
+        sk = f"{name} N={info['N']} HW={info['HW']} O={info['O']} I={info['I']} taps={info['taps']}"
+        per_shape.setdefault(sk, []).append((name, info, s.elapsed_time(e)))
+    for sk, lst in per_shape.items():
+        ds = sorted(d for _, _, d in lst)
+        med = ds[len(ds) // 2]
+        for name, info, d in lst:
+            d = min(d, med)
+            sh = shapes.setdefault(sk, [0.0, 0])
+            sh[0] += d; sh[1] += 1
+            a = agg.setdefault(name, dict(ms=0.0, flops=0.0, n=0, dtype=info["dtype"]))
+            a["ms"] += d
+            a["flops"] += conv_flops(info)
+            a["n"] += 1
     if not agg:
         return None, {}
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
@@ -96,12 +108,14 @@ def roofline_leg(step_fn, n_steps):
     ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
     table = {k: dict(launches_per_step=v["n"] / n_steps, avg_us=1e3 * v["ms"] / v["n"], ms_per_step=v["ms"] / n_steps,
                      tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in agg.items()}
+    table["_by_shape_ms_per_step"] = {k: [round(v[0] / n_steps, 3), v[1] / n_steps]
+                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:25]}
     return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                 traffic=None, avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps,
                 method="HIP events around each launch on the launch stream (includes ~launch gap); see profiles/"), table
 
 
-def cpu_baseline(cfg_id, kw, module, seconds=20.0):
+def cpu_baseline(cfg_id, kw, module, seconds=15.0):
     """The CPU oracle (port of the reference algorithm) timed on the host cores on a bounded sample: B = 8 samples per
     step, eval-mode fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
     from oracle import hdmoe_oracle as O
@@ -122,8 +136,13 @@ def cpu_baseline(cfg_id, kw, module, seconds=20.0):
                top_k=kw["top_k"], sigma_data=kw["sigma_data"])
     B = 8
     inp = make_inputs(kw, B, "cpu", 99, module)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))        # the GPU box gives one GPU a 16-core CPU share; more threads only oversubscribe
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
     lc = C.loss_configs
     times = []
     t_end = time.time() + seconds
@@ -136,7 +155,8 @@ def cpu_baseline(cfg_id, kw, module, seconds=20.0):
         for v in P.values():
             v.grad = None
         times.append(time.time() - t0)
-        if len(times) >= 12:
+        print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
+        if len(times) >= 8:
             break
     med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
     return med, B, cores, len(times)
@@ -192,6 +212,11 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # the step builds ~4k autograd nodes; CPython's cyclic GC would stall the launch thread for ~10 ms every few steps.
+    # Collect now and keep the collector off inside the timed region (tensors are freed by reference counting).
+    gc.collect()
+    gc.disable()
+    mem0 = torch.cuda.memory_allocated()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -208,7 +233,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
-    loss_val = float(loss["loss"])
+    mem_growth = torch.cuda.memory_allocated() - mem0
+    gc.enable()
+    loss_val = float(loss["loss"].detach())
 
     roof, table = (None, {})
     cpu = None
@@ -228,7 +255,7 @@ def main():
         dist.barrier()
     if rank == 0:
         line = {
-            "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4) if False else round(1e3 / ms * 1.0, 4),
+            "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4),
             "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bc["dtype"] == "bf16" else "f32",
             "data": "synthetic", "samples_per_sec": round(world * B * 1e3 / ms, 1),
@@ -237,11 +264,10 @@ def main():
                                    f"{kw['num_experts']} experts top-{kw['top_k']}, per-GPU batch {B}, train mode",
                        "global_batch": world * B, "parallelism": f"dp{world}", "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if world > 1 else ""), "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32", "loss": round(loss_val, 5), "grad_bytes": buckets.nbytes()},
+                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "grad_bytes": buckets.nbytes()},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        # whole-job throughput: every rank runs one B-sample step per step time (weak scaling) -> steps/s aggregate = world / t
-        line["value"] = round(world * 1e3 / ms, 4)
+        # value = whole-job throughput: every rank runs one B-sample step per step time (weak scaling) => world / t steps/s
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -67,11 +67,22 @@ def _timed(kind: str, info: dict, name: str, *args):
 
 
 def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
+    """Shape record of one launch + the kernel instantiation hdmoe_conv_fwd will pick (mirrors csrc/conv.hip)."""
     esz = x.element_size()
     vec = cphys % (16 // esz) == 0
-    nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
+    tname = "float" if x.dtype == torch.float32 else "__bf16"
+    tw = min(Wo, 256)
+    th = max(1, min(256 // tw, Ho))
+    nt = 1 if Cstore <= 32 else 2
+    lds = 80 * ((th + max(khs) - 1) * (tw + max(kws) - 1) + max(kws) * 32 * nt)
+    if Ho * Wo >= 64 and lds <= 64 * 1024:
+        fwd_name = f"conv_fwd2_kernel<{tname}, {nt}, {'true' if vec else 'false'}>"
+    else:
+        nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
+        fwd_name = f"conv_fwd_kernel<{tname}, {nb}, {'true' if vec else 'false'}>"
     return dict(dtype=str(x.dtype).replace("torch.", ""), seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)],
-                nb=nb, vec=vec)
+                fwd_name=fwd_name, wgrad_name=f"conv_wgrad2_kernel<{tname}, *> ({len(set(zip(khs, kws)))} launch(es) per call)")
+
 
 def _kernel_hw(w: Tensor):
     if w.ndim == 4:
