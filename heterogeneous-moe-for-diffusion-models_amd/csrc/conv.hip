@@ -363,6 +363,160 @@ __global__ __launch_bounds__(256) void conv_fwd2_kernel(ConvArgs a, int TH, int 
   }
 }
 
+// ------------------------------------------------------------------ conv forward / dgrad v3: v2 + register prefetch
+// Same tiling as v2, but the K walk is a flat sequence of stages (64-byte channel chunk x group of `tg` kernel rows) and
+// the global loads of stage s+1 (weights, plus the halo tile when a new chunk starts) are issued into registers right
+// after stage s is published, so they fly under stage s's MFMAs (guide G15, register-staged "issue early / write late").
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg) {
+  constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16, NCH = KC / VW;
+  constexpr int NWR = 9, NHR = 7;                           // 16-B chunks per thread held in registers (weights / halo)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sA = reinterpret_cast<T*>(smem_raw);                    // [halo px][PSE]
+  T* sB = sA + (long)halo_cap * PSE;                         // [tg*kw][32*NT][PSE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int g = find_group(a.seg, a.ngroups, n);
+  if (g < 0) return;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int nbase = blockIdx.z * (32 * NT);
+  const int kh = a.kh[g], kw = a.kw[g], pt = a.pt[g], pl = a.pl[g];
+  const int HWp = TW + kw - 1, HHp = TH + kh - 1;
+  const int npx = TH * TW;
+  const int nhal = HHp * HWp * NCH;
+  const int magic_hw = (1 << 20) / HWp + 1;
+  const T* x = (const T*)a.x + (long)n * a.H * a.W * a.Cphys;
+  const T* w = (const T*)a.w + (long)g * a.wstride;
+  const T zero = from_f<T>(0.f);
+
+  int abase[CV2_MT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m) {
+    const int q = wave * (32 * CV2_MT) + m * 32 + r;
+    const int qc = q < npx ? q : npx - 1;
+    const int ty = qc / TW, tx = qc - ty * TW;
+    abase[m] = (ty * HWp + tx) * PSE + 8 * h;
+  }
+  f32x16 acc[CV2_MT][NT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[m][b] = (f32x16)(0.f);
+
+  const int spc = (kh + tg - 1) / tg;                        // stages per channel chunk
+  const int nstages = ((a.Ipad + KC - 1) / KC) * spc;
+  uint4 rw[NWR], rh[NHR];
+  auto prefetch = [&](int st) {
+    const int c0 = (st / spc) * KC, ky0 = (st % spc) * tg;
+    const int nrows = min(tg, kh - ky0) * kw * 32 * NT;
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+      const int e = tid + k * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < nrows * NCH) {
+        const int cc = (e % NCH) * VW, row = e / NCH;
+        const int co = row % (32 * NT), tap = ky0 * kw + row / (32 * NT);
+        if (nbase + co < a.Cout && c0 + cc < a.Ipad)
+          v = *reinterpret_cast<const uint4*>(w + ((long)tap * a.Cout + nbase + co) * a.Ipad + c0 + cc);
+      }
+      rw[k] = v;
+    }
+    if (ky0 == 0) {
+#pragma unroll
+      for (int k = 0; k < NHR; ++k) {
+        const int e = tid + k * 256;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (e < nhal) {
+          const int px = e / NCH, cc = (e - px * NCH) * VW;
+          const int hy = (int)(((unsigned)px * (unsigned)magic_hw) >> 20), hx = px - hy * HWp;
+          const int iy = ty0 + hy - pt, ix = tx0 + hx - pl, ci = c0 + cc;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            const T* src = x + ((long)iy * a.W + ix) * a.Cphys + ci;
+            if (ci + VW <= a.Cphys) v = *reinterpret_cast<const uint4*>(src);
+            else {
+              T tmp[VW];
+#pragma unroll
+              for (int j = 0; j < VW; ++j) {
+                T e2 = zero;
+                if (ci + j < a.Cphys) e2 = src[j];
+                else if (a.ones && ci + j == a.Cphys) e2 = from_f<T>(1.f);
+                tmp[j] = e2;
+              }
+              v = *reinterpret_cast<const uint4*>(tmp);
+            }
+          }
+        }
+        rh[k] = v;
+      }
+    }
+  };
+
+  prefetch(0);
+  for (int st = 0; st < nstages; ++st) {
+    const int ky0 = (st % spc) * tg;
+    const int tgr = min(tg, kh - ky0);
+    const int nrows = tgr * kw * 32 * NT;
+    __syncthreads();                                         // readers of the previous stage are done
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+      const int e = tid + k * 256;
+      if (e < nrows * NCH) *reinterpret_cast<uint4*>(sB + (e / NCH) * PSE + (e % NCH) * VW) = rw[k];
+    }
+    if (ky0 == 0) {
+#pragma unroll
+      for (int k = 0; k < NHR; ++k) {
+        const int e = tid + k * 256;
+        if (e < nhal) *reinterpret_cast<uint4*>(sA + (e / NCH) * PSE + (e % NCH) * VW) = rh[k];
+      }
+    }
+    __syncthreads();
+    if (st + 1 < nstages) prefetch(st + 1);
+    for (int kyl = 0; kyl < tgr; ++kyl) {
+      for (int kx = 0; kx < kw; ++kx) {
+        const int aoff = ((ky0 + kyl) * HWp + kx) * PSE;
+        const T* bt = sB + ((kyl * kw + kx) * 32 * NT + r) * PSE + 8 * h;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+          Frag8<T> fa[CV2_MT], fb[NT];
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m) load8(fa[m], sA + abase[m] + aoff + 16 * s2);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) load8(fb[b], bt + b * 32 * PSE + 16 * s2);
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) mma32(acc[m][b], fa[m], fb[b]);
+        }
+      }
+    }
+  }
+  const long img = (long)n * a.Ho * a.Wo;
+  T* y = (T*)a.y;
+  const T* res = (const T*)a.res;
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int co = nbase + 32 * b + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int q = wave * (32 * CV2_MT) + m * 32 + acc_row(reg, lane);
+        if (q < npx && co < a.Cstore) {
+          const int ty = q / TW, tx = q - ty * TW;
+          const int oy = ty0 + ty, ox = tx0 + tx;
+          if (oy < a.Ho && ox < a.Wo) {
+            const long idx = (img + (long)oy * a.Wo + ox) * a.Cstore + co;
+            float v = a.alpha * acc[m][b][reg];
+            if (res) v += a.beta * to_f(res[idx]);
+            y[idx] = from_f<T>(v);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const void* x;       // [N][H][W][Cphys]
@@ -809,6 +963,23 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     const size_t lds = (size_t)80 * (halo_cap + maxkw * 32 * NT);
     const bool vec = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
     dim3 grid(tiles_y * tiles_x, N, cdiv(Cstore, 32 * NT));
+    // v3 (register prefetch): rows of weights per stage <= 576 (9 chunks/thread), halo <= 448 px (7 chunks/thread)
+    if (vec && halo_cap * 4 <= 7 * 256 && maxkw * 32 * NT <= 576 && !getenv("HDMOE_CONV_V2")) {
+      int tg = 576 / (maxkw * 32 * NT);
+      if (tg > maxkh) tg = maxkh;
+      while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;
+      const size_t lds3 = (size_t)80 * (halo_cap + tg * maxkw * 32 * NT);
+      if (lds3 <= 64 * 1024) {
+        if (dtype == HDMOE_F32) {
+          if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<float, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+          else hipLaunchKernelGGL((conv_fwd3_kernel<float, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+        } else {
+          if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+          else hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+        }
+        return hdmoe_launch_status();
+      }
+    }
     if (lds <= 64 * 1024 && grid.x <= 65535 * 32) {
 #define CV2_LAUNCH(TT, NTv)                                                                                                   \
   do { if (vec) hipLaunchKernelGGL((conv_fwd2_kernel<TT, NTv, true>), grid, dim3(256), lds, stream, a, TH, TW, tiles_x, halo_cap);  \

@@ -75,7 +75,10 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
     th = max(1, min(256 // tw, Ho))
     nt = 1 if Cstore <= 32 else 2
     lds = 80 * ((th + max(khs) - 1) * (tw + max(kws) - 1) + max(kws) * 32 * nt)
-    if Ho * Wo >= 64 and lds <= 64 * 1024:
+    halo = (th + max(khs) - 1) * (tw + max(kws) - 1)
+    if Ho * Wo >= 64 and vec and halo * 4 <= 7 * 256 and max(kws) * 32 * nt <= 576:
+        fwd_name = f"conv_fwd3_kernel<{tname}, {nt}>"
+    elif Ho * Wo >= 64 and lds <= 64 * 1024:
         fwd_name = f"conv_fwd2_kernel<{tname}, {nt}, {'true' if vec else 'false'}>"
     else:
         nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
