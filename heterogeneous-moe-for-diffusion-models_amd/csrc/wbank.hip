@@ -1,0 +1,108 @@
+// Multi-tensor weight bank: every MP_Conv weight of a model is prepared by ONE launch per forward (normalise -> gain/sqrt(fan_in)
+// -> cast -> forward image [tap][O][Ipad] + flipped dgrad image [tap'][I][Opad]) and every weight gradient is finished by ONE
+// launch per backward (normalisation backward of the [tap][O][I] wgrad slab, accumulated straight into the parameter's .grad).
+// Same arithmetic as wprep_fwd / wprep_bwd in conv.hip (reference models/model_internals.py:253-259), ~500 launches per step fewer.
+#include "common.h"
+#include "hdmoe.h"
+
+namespace {
+
+struct __attribute__((aligned(8))) WBDesc {   // mirrored byte-for-byte by hdmoe_hip/bank.py (numpy structured dtype)
+  unsigned long long w_raw, wf, wd, G, dw;   // device addresses
+  int O, I, kh, kw, Ipad, Opad, dtype, normalize, mutate_ok, pad0;
+  float gain, out_scale;
+};
+
+template <typename T> DEVI void wb_store(void* base, long idx, float v) { ((T*)base)[idx] = from_f<T>(v); }
+
+__global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, const int2* rows, int mutate) {
+  __shared__ float sm[16];
+  const int2 ro = rows[blockIdx.x];
+  const WBDesc d = descs[ro.x];
+  const int o = ro.y, tid = threadIdx.x;
+  const int taps = d.kh * d.kw, fan = d.I * taps;
+  float* w = (float*)d.w_raw + (long)o * fan;
+  float scale = 1.f;
+  if (d.normalize) {
+    const float c = rsqrtf((float)fan);
+    float ss = 0.f;
+    for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; ss += v * v; }
+    ss = block_sum(ss, sm);
+    float inv = 1.f / (1e-4f + sqrtf(ss) * c);
+    if (mutate && d.mutate_ok) {
+      for (int e = tid; e < fan; e += blockDim.x) w[e] = w[e] * inv;
+      __syncthreads();
+      float s2 = 0.f;
+      for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; s2 += v * v; }
+      s2 = block_sum(s2, sm);
+      inv = 1.f / (1e-4f + sqrtf(s2) * c);
+    }
+    scale = inv * d.gain * c;
+  }
+  const bool f32 = d.dtype == HDMOE_F32;
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e - i * taps;
+    const float v = w[e] * scale;
+    const long fi = ((long)t * d.O + o) * d.Ipad + i;
+    const long di = ((long)(taps - 1 - t) * d.I + i) * d.Opad + o;
+    if (f32) { wb_store<float>((void*)d.wf, fi, v); if (d.wd) wb_store<float>((void*)d.wd, di, v); }
+    else { wb_store<bf16>((void*)d.wf, fi, v); if (d.wd) wb_store<bf16>((void*)d.wd, di, v); }
+  }
+}
+
+__global__ __launch_bounds__(128) void wbank_bwd_kernel(const WBDesc* descs, const int2* rows) {
+  __shared__ float sm[16];
+  const int2 ro = rows[blockIdx.x];
+  const WBDesc d = descs[ro.x];
+  const int o = ro.y, tid = threadIdx.x;
+  const int taps = d.kh * d.kw, fan = d.I * taps;
+  const float* w = (const float*)d.w_raw + (long)o * fan;
+  const float* G = (const float*)d.G;
+  float* dw = (float*)d.dw + (long)o * fan;
+  if (!d.normalize) {
+    for (int e = tid; e < fan; e += blockDim.x) {
+      const int i = e / taps, t = e - i * taps;
+      dw[e] += d.out_scale * G[((long)t * d.O + o) * d.I + i];
+    }
+    return;
+  }
+  const float c = rsqrtf((float)fan);
+  float ss = 0.f, gw = 0.f;
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e - i * taps;
+    const float v = w[e];
+    ss += v * v;
+    gw += v * G[((long)t * d.O + o) * d.I + i];
+  }
+  ss = block_sum(ss, sm);
+  gw = block_sum(gw, sm);
+  const float n = sqrtf(ss);
+  const float dd = 1e-4f + n * c;
+  const float s = d.gain * c;
+  const float k1 = d.out_scale * s / dd;
+  const float k2 = n > 0.f ? d.out_scale * s * c * gw / (dd * dd * n) : 0.f;
+  for (int e = tid; e < fan; e += blockDim.x) {
+    const int i = e / taps, t = e - i * taps;
+    dw[e] += k1 * G[((long)t * d.O + o) * d.I + i] - k2 * w[e];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdmoe_wbank_desc_bytes(void) { return (int)sizeof(WBDesc); }
+
+// descs: device array of WBDesc; rows: device int32 pairs (descriptor index, output row); nrows blocks
+int hdmoe_wbank_prep(const void* descs, const int* rows, int nrows, int mutate, hipStream_t stream) {
+  if (nrows < 1) return HDMOE_OK;
+  hipLaunchKernelGGL(wbank_prep_kernel, dim3(nrows), dim3(128), 0, stream, (const WBDesc*)descs, (const int2*)rows, mutate);
+  return hdmoe_launch_status();
+}
+int hdmoe_wbank_bwd(const void* descs, const int* rows, int nrows, hipStream_t stream) {
+  if (nrows < 1) return HDMOE_OK;
+  hipLaunchKernelGGL(wbank_bwd_kernel, dim3(nrows), dim3(128), 0, stream, (const WBDesc*)descs, (const int2*)rows);
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Multi-tensor weight bank (host side of csrc/wbank.hip).
+
+A model's MP_Conv weights are tiny (<= 0.8 MB each) but there are ~250 of them; preparing each one per layer costs two
+kernel launches in the forward and one plus a gradient accumulation in the backward.  The bank registers every
+(weights, dtype, gain, alpha) call site the first time it is used and from the next step on
+  * prepares ALL forward / dgrad weight images with one launch at the start of the forward (`begin_step`),
+  * lets every wgrad accumulate into one pre-zeroed slab, and
+  * turns the slab into parameter gradients with one launch queued at the end of the backward pass (`_finish`),
+    accumulating straight into ``p.grad`` (DDP-style bucket views or the bank's own flat buffer).
+Layers whose gain is a learnable tensor (Unet_expert.out_gain) and one-off call sites keep the per-layer path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import call, dtype_code, lib
+
+_DESC = np.dtype([("w_raw", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("G", "<u8"), ("dw", "<u8"),
+                  ("O", "<i4"), ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("Ipad", "<i4"), ("Opad", "<i4"),
+                  ("dtype", "<i4"), ("normalize", "<i4"), ("mutate_ok", "<i4"), ("pad0", "<i4"),
+                  ("gain", "<f4"), ("out_scale", "<f4")])
+
+ACTIVE: Optional["WeightBank"] = None
+
+
+class Entry:
+    __slots__ = ("params", "dtype", "gain", "alpha", "normalize", "O", "I", "khs", "kws", "Ipad", "Opad", "wstride", "wdstride",
+                 "gsizes", "wf", "wd", "G", "ready", "used_bwd")
+
+    def __init__(self, params, dtype, gain, alpha, normalize):
+        self.params = tuple(params)
+        self.dtype, self.gain, self.alpha, self.normalize = dtype, gain, alpha, normalize
+        w0 = params[0]
+        self.O, self.I = int(w0.shape[0]), int(w0.shape[1])
+        self.khs = [int(w.shape[2]) if w.ndim == 4 else 1 for w in params]
+        self.kws = [int(w.shape[3]) if w.ndim == 4 else 1 for w in params]
+        self.Ipad = (self.I + 15) // 16 * 16
+        self.Opad = (self.O + 15) // 16 * 16
+        taps = max(a * b for a, b in zip(self.khs, self.kws))
+        self.wstride, self.wdstride = taps * self.O * self.Ipad, taps * self.I * self.Opad
+        self.gsizes = [a * b * self.O * self.I for a, b in zip(self.khs, self.kws)]
+        self.wf = self.wd = None
+        self.G: List[torch.Tensor] = []
+        self.ready = False
+        self.used_bwd = False
+
+
+class WeightBank:
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.entries: Dict[tuple, Entry] = {}
+        self._param_owner: Dict[int, tuple] = {}
+        self._dirty = False
+        self._built_ptrs: Optional[tuple] = None
+        self._descs = self._rows = None
+        self._nrows = 0
+        self._gflat = self._gradflat = None
+        self._cb_queued = False
+        self._keep: list = []
+        if lib().hdmoe_wbank_desc_bytes() != _DESC.itemsize:
+            raise RuntimeError("WBDesc layout mismatch between csrc/wbank.hip and hdmoe_hip/bank.py")
+
+    # ------------------------------------------------------------------------------------------------- registration
+    def lookup(self, weights: Sequence[torch.Tensor], dtype: torch.dtype, gain: float, alpha: float, normalize: bool) -> Optional[Entry]:
+        key = (tuple(id(w) for w in weights), dtype, float(gain), float(alpha), bool(normalize))
+        ent = self.entries.get(key)
+        if ent is not None:
+            return ent if ent.ready else None
+        for w in weights:                                   # a parameter may live in one entry only (in-place train-mode
+            if self._param_owner.get(id(w), key) != key:    # renormalisation must have a single writer)
+                return None
+        if not all(isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 for w in weights):
+            return None
+        for w in weights:
+            self._param_owner[id(w)] = key
+        self.entries[key] = Entry(weights, dtype, gain, alpha, normalize)
+        self._dirty = True
+        return None                                          # usable from the next begin_step on
+
+    # ------------------------------------------------------------------------------------------------- build
+    def _ptr_signature(self):
+        sig = []
+        for ent in self.entries.values():
+            for p in ent.params:
+                sig.append(p.data_ptr())
+                sig.append(0 if p.grad is None else p.grad.data_ptr())
+        return tuple(sig)
+
+    def _alloc(self):
+        """(Re)allocate the weight images, the wgrad slab and the bank-owned gradient buffer (entries changed)."""
+        dev = self.device
+        ents = list(self.entries.values())
+        gtotal = sum(sum(e.gsizes) for e in ents)
+        self._gflat = torch.zeros(max(gtotal, 1), dtype=torch.float32, device=dev)
+        goff = 0
+        for ent in ents:
+            G = len(ent.params)
+            ent.wf = torch.zeros(G * ent.wstride, dtype=ent.dtype, device=dev)        # pads stay zero for ever
+            ent.wd = torch.zeros(G * ent.wdstride, dtype=ent.dtype, device=dev)
+            ent.G = []
+            for g in range(G):
+                ent.G.append(self._gflat[goff:goff + ent.gsizes[g]])
+                goff += ent.gsizes[g]
+        params = [p for e in ents for p in e.params]
+        self._gradflat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        self._gradviews = {}
+        off = 0
+        for p in params:
+            self._gradviews[id(p)] = self._gradflat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._dirty = False
+
+    def _make_descs(self):
+        """Pointer table for the two multi-tensor kernels (parameters' .grad may have been replaced since last step)."""
+        ents = list(self.entries.values())
+        cleared = False
+        for e in ents:
+            for p in e.params:
+                if p.grad is None:                      # zero_grad(set_to_none=True): hand out our flat views again
+                    p.grad = self._gradviews[id(p)]
+                    cleared = True
+        if cleared:
+            self._gradflat.zero_()
+        descs = np.zeros(sum(len(e.params) for e in ents), dtype=_DESC)
+        rows = []
+        di = 0
+        for ent in ents:
+            esz = 2 if ent.dtype == torch.bfloat16 else 4
+            for g, p in enumerate(ent.params):
+                d = descs[di]
+                d["w_raw"], d["dw"], d["G"] = p.data_ptr(), p.grad.data_ptr(), ent.G[g].data_ptr()
+                d["wf"] = ent.wf.data_ptr() + g * ent.wstride * esz
+                d["wd"] = ent.wd.data_ptr() + g * ent.wdstride * esz
+                d["O"], d["I"], d["kh"], d["kw"] = ent.O, ent.I, ent.khs[g], ent.kws[g]
+                d["Ipad"], d["Opad"], d["dtype"], d["normalize"] = ent.Ipad, ent.Opad, dtype_code(ent.dtype), int(ent.normalize)
+                d["mutate_ok"], d["gain"], d["out_scale"] = 1, ent.gain, ent.alpha
+                rows.extend((di, o) for o in range(ent.O))
+                di += 1
+            ent.ready = True
+        self._descs = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)
+        self._rows = torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).contiguous().to(self.device)
+        self._nrows = len(rows)
+        self._built_ptrs = self._ptr_signature()
+
+    # ------------------------------------------------------------------------------------------------- per step
+    def begin_step(self, training: bool):
+        """Call at the start of a top-level forward: prepares every registered weight image in one launch."""
+        global ACTIVE
+        ACTIVE = self
+        if not self.entries:
+            return
+        if self._dirty:
+            self._alloc()
+            self._built_ptrs = None
+        if self._built_ptrs is None or self._built_ptrs != self._ptr_signature():
+            self._make_descs()
+        self._gflat.zero_()
+        for e in self.entries.values():
+            e.used_bwd = False
+        call("hdmoe_wbank_prep", self._descs, self._rows, self._nrows, 1 if training else 0)
+
+    def note_backward(self, ent: Entry):
+        ent.used_bwd = True
+        if not self._cb_queued:
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+
+    def _finish(self):
+        """Runs once at the end of the backward pass: all weight gradients in one launch."""
+        self._cb_queued = False
+        call("hdmoe_wbank_bwd", self._descs, self._rows, self._nrows)
+
+
+def bank_for(module: torch.nn.Module) -> WeightBank:
+    """The bank attached to a top-level module (created on first use)."""
+    b = getattr(module, "_hdmoe_bank", None)
+    dev = next(module.parameters()).device
+    if b is None or b.device != dev:
+        b = WeightBank(dev)
+        object.__setattr__(module, "_hdmoe_bank", b)
+    return b
+
+
+def deactivate():
+    global ACTIVE
+    ACTIVE = None

@@ -12,6 +12,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
+from . import bank as _bank
 from ._lib import call, dtype_code
 
 Tensor = torch.Tensor
@@ -122,12 +123,20 @@ class _MPConvFn(torch.autograd.Function):
         Opad = (O + 15) // 16 * 16
         taps = max(a * b for a, b in zip(khs, kws))
         wstride, wdstride = taps * O * Ipad, taps * I * Opad
-        wf = torch.empty(G * wstride, dtype=x.dtype, device=x.device)
-        # the flipped dgrad image is produced by the same prep launch when the input needs a gradient
-        wd = torch.empty(G * wdstride, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
-        call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
-             1 if normalize else 0, 1 if training else 0, 1, _dt(x))
+        ent = None
+        if _bank.ACTIVE is not None and gains is None:
+            ent = _bank.ACTIVE.lookup(weights, x.dtype, gain_val, alpha, normalize)
+        if ent is not None:                                   # images already prepared by the bank's single launch
+            wf, wd = ent.wf, ent.wd
+        else:
+            wf = torch.empty(G * wstride, dtype=x.dtype, device=x.device)
+            # the flipped dgrad image is produced by the same prep launch when the input needs a gradient
+            wd = torch.empty(G * wdstride, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+            call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
+                 1 if normalize else 0, 1 if training else 0, 1, _dt(x))
         ctx.wd = wd
+        ctx.ent = ent
+        ctx.bank = _bank.ACTIVE if ent is not None else None
         y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
         _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
                seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
@@ -163,7 +172,12 @@ class _MPConvFn(torch.autograd.Function):
             call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
         dws: List[Optional[Tensor]] = [None] * G
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
-        if need_w:
+        if need_w and ctx.ent is not None:
+            # bank path: accumulate into the bank's slab; one multi-tensor launch at the end of backward finishes every gradient
+            _timed("conv_wgrad", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_wgrad", x, dy, ctx.ent.G, seg, G, N, H, W,
+                   Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
+            ctx.bank.note_backward(ctx.ent)
+        elif need_w:
             sizes = [khs[g] * kws[g] * O * I for g in range(G)]
             Gflat = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)           # one memset for all groups
             Gs, off = [], 0

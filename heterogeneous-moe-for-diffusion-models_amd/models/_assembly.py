@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 import hdmoe_hip
+from hdmoe_hip import bank as wbank
 from hdmoe_hip import ops
 from models import model_components as m
 from models import model_internals as util
@@ -170,6 +171,15 @@ class _PrecondBase(nn.Module):
 
     def _forward(self, x: Tensor, sigma: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor, zeta,
                  return_log_var: bool, **kw):
+        B = x.shape[0]
+        wbank.bank_for(self).begin_step(self.training)                      # all weight images: one launch
+        try:
+            return self._forward_impl(x, sigma, text_emb, Unet_router_mask, Vit_router_mask, zeta, return_log_var, **kw)
+        finally:
+            wbank.deactivate()
+
+    def _forward_impl(self, x: Tensor, sigma: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor, zeta,
+                      return_log_var: bool, **kw):
         B = x.shape[0]
         coef = ops.edm_coeffs(sigma, self.sigma_data, B)                    # rows: c_skip, c_out, c_in, c_noise
         c_skip, c_out, c_in, c_noise = coef[0], coef[1], coef[2], coef[3]

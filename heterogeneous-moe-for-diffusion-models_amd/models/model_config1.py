@@ -6,6 +6,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from hdmoe_hip import bank as wbank
 from hdmoe_hip import ops
 from models._assembly import _HDMOEMBase, _PrecondBase, router_to_unet_experts   # noqa: F401  (re-exported helper)
 
@@ -29,8 +30,10 @@ class HDMOEM(_HDMOEMBase):
 
     def forward(self, x: Tensor, time_vec: Tensor, text_emb: Tensor, Unet_router_mask: Tensor, Vit_router_mask: Tensor,
                 zeta: float, alpha_routing: float = 10):
+        wbank.bank_for(self).begin_step(self.training)
         res = self._fwd(ops.to_nhwc(ops.cast(x, torch.float32)), time_vec, text_emb, Unet_router_mask, Vit_router_mask, zeta,
                         alpha_routing=alpha_routing)
+        wbank.deactivate()
         return self._public(res)
 
 

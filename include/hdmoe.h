@@ -65,6 +65,13 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
                      int Ho, int Wo, int Cin, int Cphys, int Cout, int stride, int ones, const int* kh, const int* kw,
                      const int* pt, const int* pl, int dtype, HS stream);
 
+/* Multi-tensor weight bank: one prep launch per forward and one gradient-finish launch per backward for ALL MP_Conv weights
+ * of a model.  descs: device array of descriptors (layout = hdmoe_wbank_desc_bytes() bytes each, see csrc/wbank.hip);
+ * rows: device int32 pairs (descriptor index, output-channel row), one workgroup per pair. */
+int hdmoe_wbank_desc_bytes(void);
+int hdmoe_wbank_prep(const void* descs, const int* rows, int nrows, int mutate, HS stream);
+int hdmoe_wbank_bwd(const void* descs, const int* rows, int nrows, HS stream);
+
 /* ---- K4/K7: pointwise, broadcast, relayout  (model_internals.py:33-127, model_components.py:232-253) ----- */
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, HS stream);      /* a*x + b*y (y may be NULL) : mp_sum */
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, HS stream);                     /* a*x + c */

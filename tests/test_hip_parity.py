@@ -321,6 +321,39 @@ def test_full_model_fp32_golden(golden_full):
             close_scaled(pg[n], gref, 2e-3, msg=n)
 
 
+def test_full_model_weight_bank_second_step(golden_full):
+    """From the second forward on, all weight images / weight gradients go through the multi-tensor bank
+    (hdmoe_hip/bank.py): outputs and gradients must still match the reference's golden vectors."""
+    import hdmoe_hip
+    from oracle import hdmoe_oracle as O
+    from models import model_config1, model_config2
+    g = golden_full
+    hdmoe_hip.set_compute_dtype(torch.float32)
+    cls = (model_config1 if g["variant"] == 1 else model_config2).preconditioned_HDMOEM
+    model = load_into(cls(**g["cfg"]), g["state"])
+    lc = g["loss_cfg"]
+    for it in range(3):
+        model.zero_grad(set_to_none=(it == 1))               # exercise both zero_grad flavours
+        x = dev(g["x"]).requires_grad_(True)
+        out = model(x=x, sigma=dev(g["sigma"]), text_emb=dev(g["text"]), Unet_router_mask=dev(g["unet_mask"]),
+                    Vit_router_mask=dev(g["vit_mask"]), zeta=0.0, return_log_var=True, **g["extra"])
+        outc = {k_: (v.detach().cpu().requires_grad_(True) if v is not None else None) for k_, v in out.items()}
+        O.edm_loss(outc, g["x0"], g["cfg"]["num_experts"], lc["unet_bal"], lc["vit_bal"], lc["z_bal"])["loss"].backward()
+        keys = [k_ for k_, v in outc.items() if v is not None and v.grad is not None]
+        torch.autograd.backward([out[k_] for k_ in keys], [outc[k_].grad.to(DEV) for k_ in keys])
+    bank = model._hdmoe_bank
+    assert len(bank.entries) > 50 and all(e.ready for e in bank.entries.values())
+    for key, ref in g["out"].items():
+        close_scaled(out[key], ref, 1e-3, msg=key)
+    close_scaled(x.grad, g["x_grad"], 2e-3, msg="x_grad")
+    pg = pgrads(model)
+    for n, gref in g["param_grads"].items():
+        if gref is None:
+            assert pg[n] is None or float(pg[n].abs().max()) == 0.0, n
+        else:
+            close_scaled(pg[n], gref, 2e-3, msg=n)
+
+
 def test_full_model_bf16_golden(golden_full):
     g = golden_full
     _, _, out = _run_full(g, torch.bfloat16)
