@@ -214,23 +214,24 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
         gts, gain_val = [], float(gain)
     shape = x.shape
     grouped = seg is not None
-    if x.ndim == 2:
-        x4 = x.reshape(shape[0], 1, 1, shape[1]) if grouped else x.reshape(1, 1, shape[0], shape[1])
+    if x.ndim not in (2, 3, 4):
+        raise ValueError("mp_conv: x must be 2-, 3- or 4-D")
+    pointwise = all(w.ndim == 2 or (w.shape[2] == 1 and w.shape[3] == 1) for w in ws)
+    if pointwise and not grouped and not ones:
+        # 1x1 / linear layer without per-row experts: every position is independent, so present the tensor as ONE long row
+        # of positions -- tiles are then always full (a (B,16,C) token tensor would otherwise fill 16 of 128 tile slots)
+        x4 = x.reshape(1, 1, -1, shape[-1])
+    elif x.ndim == 2:
+        x4 = x.reshape(shape[0], 1, 1, shape[1])
     elif x.ndim == 3:
         x4 = x.reshape(shape[0], 1, shape[1], shape[2])
-    elif x.ndim == 4:
-        x4 = x
     else:
-        raise ValueError("mp_conv: x must be 2-, 3- or 4-D")
-    if res is not None and x.ndim != 4:
+        x4 = x
+    if res is not None:
         res = res.reshape(x4.shape[0], x4.shape[1], x4.shape[2], -1)
     meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize))
     y = _MPConvFn.apply(x4, res, seg, meta, *ws, *gts)
-    if x.ndim == 2:
-        return y.reshape(shape[0], -1)
-    if x.ndim == 3:
-        return y.reshape(shape[0], shape[1], -1)
-    return y
+    return y.reshape(*shape[:-1], y.shape[-1])
 
 
 class _PatchEmbedFn(torch.autograd.Function):
