@@ -554,3 +554,72 @@ def test_dropout_and_noise_statistics():
     z = ops.randn_like(x, 2.0)
     assert abs(float(z.mean())) < 1e-2 and abs(float(z.std()) - 2.0) < 1e-2
     assert not torch.equal(ops.randn_like(x, 1.0), ops.randn_like(x, 1.0))   # stochastic across calls
+
+
+# ----------------------------------------------------------------------------------------------- N1: sampler drop-in
+class _MockDenoiser(torch.nn.Module):
+    """Same role as the reference's tests/test_utilities/test_sampler.py:6-23 mock."""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.num_experts = 4
+        self.scale = scale
+        self.calls = 0
+
+    def forward(self, x, sigma, text_emb, Unet_router_mask, Vit_router_mask, zeta, transition_point, softness, return_log_var=False):
+        self.calls += 1
+        assert sigma.ndim == 0 and Unet_router_mask.shape == (x.shape[0], 4) and zeta == 0
+        return {"denoised": x * self.scale}
+
+
+def test_sampler_matches_reference_update_rule():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    from EDM_sampler import EDM_Sampler
+    torch.manual_seed(0)
+    noise = torch.randn(3, 4, 8, 8, device=DEV)
+    text = torch.randn(3, 5, 16, device=DEV)
+    N = 6
+    m, gnet = _MockDenoiser(0.9).to(DEV), _MockDenoiser(0.5).to(DEV)
+    for guide in (1.0, 2.5):
+        s = EDM_Sampler(m, gnet, num_solve_steps=N, guidance=guide)
+        out = s.sample(noise, text, -1.2, 1.6)
+        # CPU restatement of the reference loop (Utils/EDM_sampler.py:73-109) with the same mock
+        i = torch.arange(N, dtype=torch.float64)
+        t = (80 ** (1 / 7) + i / (N - 1) * (0.002 ** (1 / 7) - 80 ** (1 / 7))) ** 7
+        t = torch.cat([t, torch.zeros(1, dtype=torch.float64)])
+        den = lambda x: (0.5 * x).lerp(0.9 * x, guide) if guide != 1.0 else 0.9 * x
+        x = noise.cpu().double() * t[0]
+        for k in range(N):
+            d = (x - den(x)) / t[k]
+            xn = x + (t[k + 1] - t[k]) * d
+            if k < N - 1:
+                dp = (xn - den(xn)) / t[k + 1]
+                xn = x + (t[k + 1] - t[k]) * (0.5 * d + 0.5 * dp)
+            x = xn
+        close_scaled(out, x.float(), 1e-4, msg=f"sampler guide={guide}")
+        assert torch.equal(out, s.sample(noise, text, -1.2, 1.6))          # deterministic without churn
+    assert m.calls == 2 * 2 * (2 * N - 1)
+    s = EDM_Sampler(m, gnet, num_solve_steps=N, S_churn=10.0)
+    assert not torch.equal(s.sample(noise, text, -1.2, 1.6), s.sample(noise, text, -1.2, 1.6))   # stochastic with churn
+
+
+def test_sampler_runs_on_the_real_model(golden_full):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    from EDM_sampler import EDM_Sampler
+    from models import model_config2
+    g = golden_full
+    if g["variant"] != 2:
+        pytest.skip("the sampler passes transition_point/softness: model_config2 only (reference Utils/EDM_sampler.py:43-52)")
+    model = load_into(model_config2.preconditioned_HDMOEM(**g["cfg"]), g["state"])
+    noise = torch.randn(2, 4, 16, 16, device=DEV)
+    s = EDM_Sampler(model, model, num_solve_steps=4)
+    out = s.sample(noise, dev(g["text"][:2]), -1.2, 1.6)
+    assert out.shape == (2, 4, 16, 16) and torch.isfinite(out).all()
+    # hipGraph replay of the denoiser evaluation gives the same trajectory as eager execution
+    sg = EDM_Sampler(model, model, num_solve_steps=4, use_graph=True)
+    outg = sg.sample(noise, dev(g["text"][:2]), -1.2, 1.6)
+    close_scaled(outg, out, 1e-5, msg="graph replay vs eager")
