@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default="", help="write the per-kernel table of the roofline leg to this JSON file")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,14 +201,40 @@ def main():
     buckets = GradBuckets(model, bucket_mb=16.0)            # flat fp32 grad buckets; RCCL all-reduce when world > 1
     zeta = 0.1
 
-    def step():
+    from hdmoe_hip import ops
+    from hdmoe_hip.graph import GraphedStep
+
+    def fwd_bwd():
         buckets.zero_grad()
         out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["um"], Vit_router_mask=inp["vm"],
                     zeta=zeta, return_log_var=True, **inp["extra"])
         loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
         loss["loss"].backward()
-        buckets.finish()
-        return loss
+        return loss["loss"].detach()
+
+    def eager_step():
+        ops.advance_seed(device)
+        l = fwd_bwd()
+        buckets.finish()                                    # RCCL all-reduce of the flat gradient buckets when world > 1
+        return {"loss": l}
+
+    step = eager_step
+    if not args.no_graph:
+        # the step is ~2.4k launches: replay it as one hipGraph (fwd + loss + bwd + weight-gradient finish); the gradient
+        # all-reduce stays outside the graph and runs right after the replay
+        buckets.enabled = False                             # no collectives from autograd hooks while capturing
+        try:
+            graphed = GraphedStep(fwd_bwd, device)
+        except Exception as exc:                            # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
+            graphed = None
+            args.no_graph = True
+        buckets.enabled = True
+        if graphed is not None:
+            def step():
+                l = graphed()
+                buckets.finish()
+                return {"loss": l}
 
     for _ in range(args.warmup):
         step()
@@ -241,7 +268,7 @@ def main():
     cpu = None
     if rank == 0:
         if not args.no_roofline:
-            roof, table = roofline_leg(step, 3)
+            roof, table = roofline_leg(eager_step, 3)       # per-launch events need eager launches
             if args.dump_kernels:
                 with open(args.dump_kernels, "w") as f:
                     json.dump(table, f, indent=1)
@@ -263,7 +290,7 @@ def main():
                                    f"{kw['IN_in_channels']}x{kw['IN_img_resolution']}x{kw['IN_img_resolution']} latents, "
                                    f"{kw['num_experts']} experts top-{kw['top_k']}, per-GPU batch {B}, train mode",
                        "global_batch": world * B, "parallelism": f"dp{world}", "step": "fwd + EDM_LOSS + bwd"
-                       + (" + RCCL grad all-reduce" if world > 1 else ""), "optimizer": "excluded (metric is fwd+bwd)",
+                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else "hipGraph replay", "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "grad_bytes": buckets.nbytes()},
             "roofline": roof, "cpu_baseline": cpu,
         }

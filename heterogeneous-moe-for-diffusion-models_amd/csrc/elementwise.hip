@@ -528,8 +528,19 @@ DEVI void philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o
 DEVI float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.f / 16777216.f); }
 
 // F.dropout(p): keep with prob 1-p, scale 1/(1-p); the mask is regenerated from (seed, element index) in bwd
+// the Philox key is (per-call salt) + (device step counter) * golden ratio: a captured hipGraph replays with fresh randomness
+// because the counter lives in device memory and is advanced by hdmoe_seed_advance once per step
+DEVI void mix_seed(uint32_t& lo, uint32_t& hi, const unsigned long long* seed_dev) {
+  if (seed_dev) {
+    const unsigned long long k = (((unsigned long long)hi << 32) | lo) + (*seed_dev) * 0x9E3779B97F4A7C15ull;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+  }
+}
+__global__ void seed_advance_kernel(unsigned long long* seed_dev) { *seed_dev += 1ull; }
+
 template <typename T>
-__global__ void dropout_kernel(T* out, const T* x, uint32_t seed_lo, uint32_t seed_hi, float p, long n) {
+__global__ void dropout_kernel(T* out, const T* x, uint32_t seed_lo, uint32_t seed_hi, const unsigned long long* seed_dev, float p, long n) {
+  mix_seed(seed_lo, seed_hi, seed_dev);
   const float inv = 1.f / (1.f - p);
   GRID_STRIDE(q, (n + 3) / 4) {
     uint32_t r[4];
@@ -541,7 +552,8 @@ __global__ void dropout_kernel(T* out, const T* x, uint32_t seed_lo, uint32_t se
     }
   }
 }
-__global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, float scale, long n) {
+__global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, const unsigned long long* seed_dev, float scale, long n) {
+  mix_seed(seed_lo, seed_hi, seed_dev);
   GRID_STRIDE(q, (n + 3) / 4) {
     uint32_t r[4];
     philox((uint32_t)q, (uint32_t)(q >> 32), seed_lo, seed_hi, r);
@@ -742,12 +754,17 @@ int hdmoe_take_col_pos_bwd(float* dw, const float* g, const float* w, long B, in
   L1D(take_col_pos_bwd_kernel, B, dw, g, w, E, e, B);
   return hdmoe_launch_status();
 }
-int hdmoe_dropout(void* out, const void* x, unsigned long long seed, float p, long n, int dtype, hipStream_t stream) {
+int hdmoe_dropout(void* out, const void* x, unsigned long long seed, const unsigned long long* seed_dev, float p, long n, int dtype,
+                  hipStream_t stream) {
   if (p < 0.f || p >= 1.f) return HDMOE_EINVAL;
-  DT_SWITCH(dtype, L1D(dropout_kernel<T>, (n + 3) / 4, (T*)out, (const T*)x, (uint32_t)seed, (uint32_t)(seed >> 32), p, n))
+  DT_SWITCH(dtype, L1D(dropout_kernel<T>, (n + 3) / 4, (T*)out, (const T*)x, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, p, n))
 }
-int hdmoe_randn(float* out, unsigned long long seed, float scale, long n, hipStream_t stream) {
-  L1D(randn_kernel, (n + 3) / 4, out, (uint32_t)seed, (uint32_t)(seed >> 32), scale, n);
+int hdmoe_randn(float* out, unsigned long long seed, const unsigned long long* seed_dev, float scale, long n, hipStream_t stream) {
+  L1D(randn_kernel, (n + 3) / 4, out, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, scale, n);
+  return hdmoe_launch_status();
+}
+int hdmoe_seed_advance(unsigned long long* seed_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, stream, seed_dev);
   return hdmoe_launch_status();
 }
 

@@ -35,6 +35,7 @@ class GradBuckets:
         self._pending = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
         self._next = 0                                             # collectives are issued strictly in bucket order
+        self.enabled = True                                        # False: hooks only count (e.g. while capturing a hipGraph)
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         for bi, members in enumerate(self._members):
             for p in members:
@@ -52,6 +53,8 @@ class GradBuckets:
 
     def _make_hook(self, bi):
         def hook(_p):
+            if not self.enabled:
+                return
             self._pending[bi] += 1
             # every rank must issue the same collectives in the same order, but which hooks fire (and when) depends on
             # the local routing: launch only the contiguous prefix of complete buckets, the rest waits for finish()

@@ -48,6 +48,24 @@ def _next_seed() -> int:
     return ((_seed_state["seed"] * 0x9E3779B97F4A7C15) ^ (_seed_state["ctr"] * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
 
 
+_step_counters = {}
+
+
+def step_counter(device) -> Tensor:
+    """Device-resident step counter mixed into every dropout / noise Philox key (see csrc/elementwise.hip: mix_seed)."""
+    key = torch.device(device)
+    t = _step_counters.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=key)
+        _step_counters[key] = t
+    return t
+
+
+def advance_seed(device) -> None:
+    """Call once per training step (inside the captured region when the step is a hipGraph)."""
+    call("hdmoe_seed_advance", step_counter(device))
+
+
 # =====================================================================================================
 # MP_Conv: weight prep + implicit GEMM conv (+dgrad, wgrad)
 # =====================================================================================================
@@ -771,7 +789,7 @@ class _DropoutFn(torch.autograd.Function):
     def forward(ctx, x, p, seed):
         x = _c(x)
         out = torch.empty_like(x)
-        call("hdmoe_dropout", out, x, seed, p, x.numel(), _dt(x))
+        call("hdmoe_dropout", out, x, seed, step_counter(x.device), p, x.numel(), _dt(x))
         ctx.meta = (p, seed)
         return out
 
@@ -780,7 +798,7 @@ class _DropoutFn(torch.autograd.Function):
         p, seed = ctx.meta
         g = _c(g)
         dx = torch.empty_like(g)
-        call("hdmoe_dropout", dx, g, seed, p, g.numel(), _dt(g))
+        call("hdmoe_dropout", dx, g, seed, step_counter(g.device), p, g.numel(), _dt(g))
         return dx, None, None
 
 
@@ -792,7 +810,7 @@ def dropout(x: Tensor, p: float, training: bool) -> Tensor:
 
 def randn_like(x: Tensor, scale: float) -> Tensor:
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    call("hdmoe_randn", out, _next_seed(), float(scale), out.numel())
+    call("hdmoe_randn", out, _next_seed(), step_counter(x.device), float(scale), out.numel())
     return out
 
 

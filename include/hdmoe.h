@@ -116,8 +116,11 @@ int hdmoe_adaln_fwd(float* out, const float* x, const float* cond, long B, int F
 int hdmoe_adaln_bwd(float* dx, float* dcond, const float* g, const float* x, const float* cond, long B, int F, HS stream);
 int hdmoe_take_col_pos_fwd(float* out, const float* w, long B, int E, int e, HS stream);                         /* w[:,e] where > 0 (model_config1.py:26,35) */
 int hdmoe_take_col_pos_bwd(float* dw, const float* g, const float* w, long B, int E, int e, HS stream);          /* dw pre-zeroed */
-int hdmoe_dropout(void* out, const void* x, unsigned long long seed, float p, long n, int dtype, HS stream);     /* F.dropout, model_components.py:245-246 */
-int hdmoe_randn(float* out, unsigned long long seed, float scale, long n, HS stream);                            /* randn*zeta, :155-156 */
+/* Philox key = seed + (*seed_dev) * golden (seed_dev: optional device step counter, so captured graphs replay with fresh draws) */
+int hdmoe_dropout(void* out, const void* x, unsigned long long seed, const unsigned long long* seed_dev, float p, long n, int dtype,
+                  HS stream);                                                                                    /* F.dropout, model_components.py:245-246 */
+int hdmoe_randn(float* out, unsigned long long seed, const unsigned long long* seed_dev, float scale, long n, HS stream); /* randn*zeta, :155-156 */
+int hdmoe_seed_advance(unsigned long long* seed_dev, HS stream);
 
 /* ---- K6: norms  (model_internals.py:8-30; nn.GroupNorm / nn.LayerNorm in model_components.py) ------------ */
 int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, HS stream);               /* h = mp_silu(xn), optional */
