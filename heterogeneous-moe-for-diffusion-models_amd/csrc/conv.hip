@@ -491,22 +491,26 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
       }
     }
   }
-  const long img = (long)n * a.Ho * a.Wo;
-  T* y = (T*)a.y;
-  const T* res = (const T*)a.res;
+  // ---- epilogue.  Tiles are either whole image rows (TW == Wo) or a slice of one row (TH == 1), so the tile-local pixel
+  // q maps to the linear image position ty0*Wo + tx0 + q: no per-element division (the v2 epilogue spent ~25 VALU/element).
+  const long HWo = (long)a.Ho * a.Wo;
+  const long lin0 = (long)ty0 * a.Wo + tx0;
+  T* y = (T*)a.y + (long)n * HWo * a.Cstore;
+  const T* res = a.res ? (const T*)a.res + (long)n * HWo * a.Cstore : nullptr;
+  const int qlim = (TH > 1) ? npx : min(npx, a.Wo - tx0);
 #pragma unroll
   for (int m = 0; m < CV2_MT; ++m) {
+    const int qb = wave * (32 * CV2_MT) + m * 32 + 4 * h;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int co = nbase + 32 * b + r;
+      if (co < a.Cstore) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int q = wave * (32 * CV2_MT) + m * 32 + acc_row(reg, lane);
-        if (q < npx && co < a.Cstore) {
-          const int ty = q / TW, tx = q - ty * TW;
-          const int oy = ty0 + ty, ox = tx0 + tx;
-          if (oy < a.Ho && ox < a.Wo) {
-            const long idx = (img + (long)oy * a.Wo + ox) * a.Cstore + co;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int q = qb + (reg & 3) + 8 * (reg >> 2);
+          const long lin = lin0 + q;
+          if (q < qlim && lin < HWo) {
+            const long idx = lin * a.Cstore + co;
             float v = a.alpha * acc[m][b][reg];
             if (res) v += a.beta * to_f(res[idx]);
             y[idx] = from_f<T>(v);
