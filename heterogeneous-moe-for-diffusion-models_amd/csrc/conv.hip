@@ -661,7 +661,7 @@ struct Wg2Geom {                      // launch geometry of one kernel-size clas
 };
 
 template <typename T, int OT, int MAXT, bool VEC>
-__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a, Wg2Geom gm) {
+__global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(WgradArgs a, Wg2Geom gm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int OB = 32 * OT;
   constexpr int OBP = (OT == 2 && sizeof(T) == 2) ? OB + 32 : OB;      // bank-conflict-free row stride for the tr reads
