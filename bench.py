@@ -72,6 +72,25 @@ def conv_flops(info):
     return sum((seg[g + 1] - seg[g]) * per_px * t for g, t in enumerate(info["taps"]))
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected
+    offline as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE doubled on gfx950), or None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    tbl = json.load(open(files[-1]))
+    m = re.match(r"(\w+)<(\w+), (\d+)", kernel_name)
+    keys = [kernel_name]
+    if m:                                                   # rocprof prints bf16 instantiations mangled
+        keys.append(f"{m.group(1)}IDF16bLi{m.group(3)}")
+    for k, v in tbl.items():
+        if any(key in k for key in keys):
+            return round(v["hbm_read_bytes_per_launch_corrected"] + v["hbm_write_bytes_per_launch"])
+    return None
+
+
 def roofline_leg(step_fn, n_steps):
     """Time every conv-family launch of a few extra steps with events on the launch stream; report the kernel
     instantiation with the largest total time.  achieved = sum(algorithmic FLOPs) / sum(duration)."""
@@ -111,7 +130,7 @@ def roofline_leg(step_fn, n_steps):
     table["_by_shape_ms_per_step"] = {k: [round(v[0] / n_steps, 3), v[1] / n_steps]
                                       for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:25]}
     return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                traffic=None, avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps,
+                traffic=pmc_traffic(name), avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps,
                 method="HIP events around each launch on the launch stream (includes ~launch gap); see profiles/"), table
 
 
