@@ -1054,8 +1054,19 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
         const int ibs = cdiv(Cin, WG2_IB), obs = cdiv(Cout, OB);
         // every workgroup ends with an atomic flush of its [taps][OB][32] accumulators; the flush traffic is
         // (pixel partitions) x (weight bytes) at ~1.3 TB/s, so keep the partition count near 256 / (ibs * obs) per launch
-        long parts = 384 / ((long)ibs * obs); if (parts < 8) parts = 8;
-        long upw = (units_l + parts - 1) / parts; if (upw < 1) upw = 1;
+        // Every workgroup ends with an fp32 atomic flush of its [taps][OB][32] accumulators (~1.3 TB/s chip-wide), so the
+        // flush traffic is (pixel partitions) x (weight bytes).  fp32 units are long (64-cycle MFMAs): fill the chip exactly
+        // once.  bf16 units are short and the flush dominates: fewer, longer workgroups measured best (launch_table sweeps).
+        long upw;
+        if (esz == 4) {
+            long parts = 512 / ((long)ibs * obs); if (parts < 8) parts = 8;
+            const long class_units = (units_l * gm.ngr + ngroups - 1) / ngroups;   // assume balanced routing
+            upw = (class_units + parts - 1) / parts;
+        } else {
+            long parts = 384 / ((long)ibs * obs); if (parts < 8) parts = 8;
+            upw = (units_l + parts - 1) / parts;
+        }
+        if (upw < 1) upw = 1;
         gm.upw = (int)upw;
         gm.chunks = (int)((units_l + upw - 1) / upw);
         dim3 grid(ibs, obs, gm.chunks * gm.ngr);
