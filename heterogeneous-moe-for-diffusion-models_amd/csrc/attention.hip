@@ -14,7 +14,7 @@ constexpr int TQ = 256;     // rows owned by a block (one per thread)
 constexpr int TK = 128;     // streamed rows per LDS tile
 constexpr int CH = 16;      // online-softmax chunk
 
-template <typename T, int D>
+template <typename T, int D, bool BIAS>
 __global__ __launch_bounds__(TQ) void attn_fwd_kernel(T* out, float* lse, const T* q, const T* k, const T* v, const float* bias,
                                                      int Sq, int Skv, int H, int Sb, float scale) {
   __shared__ float sk[TK * D], sv[TK * D];
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(TQ) void attn_fwd_kernel(T* out, float* lse, const 
 #pragma unroll
   for (int d = 0; d < D; ++d) { qv[d] = act ? to_f(q[((long)b * Sq + i) * E + h * D + d]) * scale : 0.f; o[d] = 0.f; }
   float m = -INFINITY, l = 0.f;
-  const float* brow = (bias && act) ? bias + ((long)h * Sb + i) * Sb : nullptr;
+  const float* brow = (BIAS && act) ? bias + ((long)h * Sb + i) * Sb : nullptr;
   for (int j0 = 0; j0 < Skv; j0 += TK) {
     const int nj = min(TK, Skv - j0);
     __syncthreads();
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(TQ) void attn_fwd_kernel(T* out, float* lse, const 
           a = 0.f;
 #pragma unroll
           for (int d = 0; d < D; ++d) a += qv[d] * sk[(c0 + c) * D + d];
-          if (brow) a += brow[j0 + c0 + c];
+          if (BIAS) a += brow[j0 + c0 + c];
         }
         s[c] = a; cm = fmaxf(cm, a);
       }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(TQ) void attn_fwd_kernel(T* out, float* lse, const 
 }
 
 // dq (+ delta, + dbias): thread = query row
-template <typename T, int D>
+template <typename T, int D, bool BIAS>
 __global__ __launch_bounds__(TQ) void attn_bwd_dq_kernel(T* dq, float* delta, float* dbias, const T* dout, const T* out, const T* q,
                                                         const T* k, const T* v, const float* lse, const float* bias, int Sq, int Skv,
                                                         int H, int Sb, float scale) {
@@ -110,11 +110,10 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dq_kernel(T* dq, float* delta, fl
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) { s += qv[d] * sk[j * D + d]; dp += dov[d] * sv[j * D + d]; }
-      if (bias) s += bias[boff + j0 + j];
+      if (BIAS) s += bias[boff + j0 + j];
       const float ds = __expf(s - ls) * (dp - dl);
 #pragma unroll
       for (int d = 0; d < D; ++d) acc[d] += ds * sk[j * D + d];
-      if (dbias) atomicAdd(&dbias[boff + j0 + j], ds);
     }
   }
   if (act) {
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dq_kernel(T* dq, float* delta, fl
 }
 
 // dk, dv: thread = key row; queries stream through LDS
-template <typename T, int D>
+template <typename T, int D, bool BIAS>
 __global__ __launch_bounds__(TQ) void attn_bwd_dkv_kernel(T* dk, T* dv, const T* dout, const T* q, const T* k, const T* v,
                                                          const float* lse, const float* delta, const float* bias, int Sq, int Skv,
                                                          int H, int Sb, float scale) {
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dkv_kernel(T* dk, T* dv, const T*
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) { s += sq[i * D + d] * kv[d]; dp += sdo[i * D + d] * vv[d]; }
-      if (bias) s += bias[((long)h * Sb + i0 + i) * Sb + j];
+      if (BIAS) s += bias[((long)h * Sb + i0 + i) * Sb + j];
       const float p = __expf(s - sl[i]);
       const float ds = p * (dp - sd[i]);
 #pragma unroll
@@ -175,11 +174,40 @@ __global__ __launch_bounds__(TQ) void attn_bwd_dkv_kernel(T* dk, T* dv, const T*
   }
 }
 
+// d(rel_pos_bias)[h][i][j] = sum_b ds[b][h][i][j].  One thread per (h, i, j) walks the batch (no atomics: with B samples
+// adding into the same H*S*S words the atomic version was 256-way contended and cost ~100 us per call on S = 64).
+template <typename T, int D>
+__global__ void attn_dbias_kernel(float* dbias, const T* dout, const T* q, const T* k, const T* v, const float* lse,
+                                  const float* delta, const float* bias, int B, int Sq, int Skv, int H, int Sb, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * Sq * Skv) return;
+  const int j = (int)(idx % Skv);
+  const int i = (int)((idx / Skv) % Sq);
+  const int h = (int)(idx / ((long)Skv * Sq));
+  const int E = H * D;
+  const float bv = bias[((long)h * Sb + i) * Sb + j];
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const T* qp = q + ((long)b * Sq + i) * E + h * D;
+    const T* dop = dout + ((long)b * Sq + i) * E + h * D;
+    const T* kp = k + ((long)b * Skv + j) * E + h * D;
+    const T* vp = v + ((long)b * Skv + j) * E + h * D;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s += to_f(qp[d]) * to_f(kp[d]); dp += to_f(dop[d]) * to_f(vp[d]); }
+    const long li = ((long)b * H + h) * Sq + i;
+    acc += __expf(s * scale + bv - lse[li]) * (dp - delta[li]);
+  }
+  dbias[((long)h * Sb + i) * Sb + j] = acc;
+}
+
 template <typename T, int D>
 int attn_fwd_launch(void* out, float* lse, const void* q, const void* k, const void* v, const float* bias, int B, int Sq, int Skv,
                     int H, int Sb, hipStream_t st) {
   dim3 grid(cdiv(Sq, TQ), H, B);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(TQ), 0, st, (T*)out, lse, (const T*)q, (const T*)k, (const T*)v, bias, Sq,
+  if (bias) hipLaunchKernelGGL((attn_fwd_kernel<T, D, true>), grid, dim3(TQ), 0, st, (T*)out, lse, (const T*)q, (const T*)k, (const T*)v, bias, Sq,
+                     Skv, H, Sb, 1.f / sqrtf((float)D));
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, D, false>), grid, dim3(TQ), 0, st, (T*)out, lse, (const T*)q, (const T*)k, (const T*)v, bias, Sq,
                      Skv, H, Sb, 1.f / sqrtf((float)D));
   return hdmoe_launch_status();
 }
@@ -188,10 +216,17 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
                     const void* k, const void* v, const float* lse, const float* bias, int B, int Sq, int Skv, int H, int Sb,
                     hipStream_t st) {
   const float scale = 1.f / sqrtf((float)D);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(cdiv(Sq, TQ), H, B), dim3(TQ), 0, st, (T*)dq, delta, dbias, (const T*)dout,
-                     (const T*)out, (const T*)q, (const T*)k, (const T*)v, lse, bias, Sq, Skv, H, Sb, scale);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), dim3(cdiv(Skv, TQ), H, B), dim3(TQ), 0, st, (T*)dk, (T*)dv, (const T*)dout,
+#define ATTN_BWD(BB)                                                                                                                  \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, BB>), dim3(cdiv(Sq, TQ), H, B), dim3(TQ), 0, st, (T*)dq, delta, dbias, (const T*)dout,  \
+                     (const T*)out, (const T*)q, (const T*)k, (const T*)v, lse, bias, Sq, Skv, H, Sb, scale);                          \
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, BB>), dim3(cdiv(Skv, TQ), H, B), dim3(TQ), 0, st, (T*)dk, (T*)dv, (const T*)dout,      \
                      (const T*)q, (const T*)k, (const T*)v, lse, delta, bias, Sq, Skv, H, Sb, scale);
+  if (bias) { ATTN_BWD(true) } else { ATTN_BWD(false) }
+  if (bias && dbias) {
+    const long nthreads = (long)H * Sq * Skv;
+    hipLaunchKernelGGL((attn_dbias_kernel<T, D>), dim3(cdiv(nthreads, 256)), dim3(256), 0, st, dbias, (const T*)dout, (const T*)q, (const T*)k,
+                       (const T*)v, lse, delta, bias, B, Sq, Skv, H, Sb, scale);
+  }
   return hdmoe_launch_status();
 }
 

@@ -1063,7 +1063,8 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
             const long class_units = (units_l * gm.ngr + ngroups - 1) / ngroups;   // assume balanced routing
             upw = (class_units + parts - 1) / parts;
         } else {
-            long parts = 384 / ((long)ibs * obs); if (parts < 8) parts = 8;
+            static const long bf16_parts = getenv("HDMOE_WG_PARTS") ? atol(getenv("HDMOE_WG_PARTS")) : 384;
+            long parts = bf16_parts / ((long)ibs * obs); if (parts < 8) parts = 8;
             upw = (units_l + parts - 1) / parts;
         }
         if (upw < 1) upw = 1;
