@@ -406,45 +406,62 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
 
   const int spc = (kh + tg - 1) / tg;                        // stages per channel chunk
   const int nstages = ((a.Ipad + KC - 1) / KC) * spc;
+  // ---- per-thread staging plan, computed ONCE per tile (the per-stage index arithmetic used to cost ~470 VALU instructions
+  // per 72 MFMAs; plain VALU issues at 4 cycles per wave64 instruction, so it -- not the MFMA pipe -- set the pace)
   uint4 rw[NWR], rh[NHR];
+  int woff[NWR], wlds[NWR];                                  // weight chunk: global offset (stage 0) / LDS offset; woff < 0 = unused
+  int hoff[NHR], hlds[NHR], hcc[NHR];                        // halo chunk: global offset (c0 = 0) / LDS offset / channel in chunk
+  const int rows_full = tg * kw * 32 * NT;
+#pragma unroll
+  for (int k = 0; k < NWR; ++k) {
+    const int e = tid + k * 256;
+    const int cc = (e % NCH) * VW, row = e / NCH;
+    const int co = row % (32 * NT), tapl = row / (32 * NT);  // tap within the stage's group of kernel rows
+    woff[k] = (row < rows_full && nbase + co < a.Cout) ? (tapl * a.Cout + nbase + co) * a.Ipad + cc : -1;
+    wlds[k] = row * PSE + cc;
+    if (woff[k] >= 0) woff[k] |= (tapl / kw) << 26;          // local kernel row in the top bits (a stage may hold fewer rows)
+  }
+#pragma unroll
+  for (int k = 0; k < NHR; ++k) {
+    const int e = tid + k * 256;
+    const int px = e / NCH, cc = (e - px * NCH) * VW;
+    const int hy = (int)(((unsigned)px * (unsigned)magic_hw) >> 20), hx = px - hy * HWp;
+    const int iy = ty0 + hy - pt, ix = tx0 + hx - pl;
+    const bool inb = e < nhal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    hoff[k] = inb ? (iy * a.W + ix) * a.Cphys + cc : -1;
+    hlds[k] = (e < nhal) ? px * PSE + cc : -1;
+    hcc[k] = cc;
+  }
+  const int wtap_stride = kw * a.Cout * a.Ipad;              // one kernel row of the [tap][Cout][Ipad] image
   auto prefetch = [&](int st) {
     const int c0 = (st / spc) * KC, ky0 = (st % spc) * tg;
-    const int nrows = min(tg, kh - ky0) * kw * 32 * NT;
+    const int tgr = min(tg, kh - ky0);
+    const T* wst = w + (long)ky0 * wtap_stride + c0;
 #pragma unroll
     for (int k = 0; k < NWR; ++k) {
-      const int e = tid + k * 256;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (e < nrows * NCH) {
-        const int cc = (e % NCH) * VW, row = e / NCH;
-        const int co = row % (32 * NT), tap = ky0 * kw + row / (32 * NT);
-        if (nbase + co < a.Cout && c0 + cc < a.Ipad)
-          v = *reinterpret_cast<const uint4*>(w + ((long)tap * a.Cout + nbase + co) * a.Ipad + c0 + cc);
-      }
+      if (woff[k] >= 0 && (woff[k] >> 26) < tgr && c0 + (wlds[k] % PSE) < a.Ipad)
+        v = *reinterpret_cast<const uint4*>(wst + (woff[k] & 0x3FFFFFF));
       rw[k] = v;
     }
     if (ky0 == 0) {
 #pragma unroll
       for (int k = 0; k < NHR; ++k) {
-        const int e = tid + k * 256;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (e < nhal) {
-          const int px = e / NCH, cc = (e - px * NCH) * VW;
-          const int hy = (int)(((unsigned)px * (unsigned)magic_hw) >> 20), hx = px - hy * HWp;
-          const int iy = ty0 + hy - pt, ix = tx0 + hx - pl, ci = c0 + cc;
-          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            const T* src = x + ((long)iy * a.W + ix) * a.Cphys + ci;
-            if (ci + VW <= a.Cphys) v = *reinterpret_cast<const uint4*>(src);
-            else {
-              T tmp[VW];
+        if (hoff[k] >= 0) {
+          const int ci = c0 + hcc[k];
+          const T* src = x + hoff[k] + c0;
+          if (ci + VW <= a.Cphys) v = *reinterpret_cast<const uint4*>(src);
+          else {
+            T tmp[VW];
 #pragma unroll
-              for (int j = 0; j < VW; ++j) {
-                T e2 = zero;
-                if (ci + j < a.Cphys) e2 = src[j];
-                else if (a.ones && ci + j == a.Cphys) e2 = from_f<T>(1.f);
-                tmp[j] = e2;
-              }
-              v = *reinterpret_cast<const uint4*>(tmp);
+            for (int j = 0; j < VW; ++j) {
+              T e2 = zero;
+              if (ci + j < a.Cphys) e2 = src[j];
+              else if (a.ones && ci + j == a.Cphys) e2 = from_f<T>(1.f);
+              tmp[j] = e2;
             }
+            v = *reinterpret_cast<const uint4*>(tmp);
           }
         }
         rh[k] = v;
@@ -456,31 +473,28 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
   for (int st = 0; st < nstages; ++st) {
     const int ky0 = (st % spc) * tg;
     const int tgr = min(tg, kh - ky0);
-    const int nrows = tgr * kw * 32 * NT;
     __syncthreads();                                         // readers of the previous stage are done
 #pragma unroll
-    for (int k = 0; k < NWR; ++k) {
-      const int e = tid + k * 256;
-      if (e < nrows * NCH) *reinterpret_cast<uint4*>(sB + (e / NCH) * PSE + (e % NCH) * VW) = rw[k];
-    }
+    for (int k = 0; k < NWR; ++k)
+      if (woff[k] >= 0 && (woff[k] >> 26) < tgr) *reinterpret_cast<uint4*>(sB + wlds[k]) = rw[k];
     if (ky0 == 0) {
 #pragma unroll
-      for (int k = 0; k < NHR; ++k) {
-        const int e = tid + k * 256;
-        if (e < nhal) *reinterpret_cast<uint4*>(sA + (e / NCH) * PSE + (e % NCH) * VW) = rh[k];
-      }
+      for (int k = 0; k < NHR; ++k)
+        if (hlds[k] >= 0) *reinterpret_cast<uint4*>(sA + hlds[k]) = rh[k];
     }
     __syncthreads();
     if (st + 1 < nstages) prefetch(st + 1);
+    // strength-reduced operand addresses: one add per tap, immediate offsets for the k-steps / N-tiles
+    const T* arow = sA + ky0 * HWp * PSE;
+    const T* bt = sB + r * PSE + 8 * h;
     for (int kyl = 0; kyl < tgr; ++kyl) {
+      const T* ap = arow;
       for (int kx = 0; kx < kw; ++kx) {
-        const int aoff = ((ky0 + kyl) * HWp + kx) * PSE;
-        const T* bt = sB + ((kyl * kw + kx) * 32 * NT + r) * PSE + 8 * h;
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) {
           Frag8<T> fa[CV2_MT], fb[NT];
 #pragma unroll
-          for (int m = 0; m < CV2_MT; ++m) load8(fa[m], sA + abase[m] + aoff + 16 * s2);
+          for (int m = 0; m < CV2_MT; ++m) load8(fa[m], ap + abase[m] + 16 * s2);
 #pragma unroll
           for (int b = 0; b < NT; ++b) load8(fb[b], bt + b * 32 * PSE + 16 * s2);
 #pragma unroll
@@ -488,7 +502,10 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
 #pragma unroll
             for (int b = 0; b < NT; ++b) mma32(acc[m][b], fa[m], fb[b]);
         }
+        ap += PSE;
+        bt += 32 * NT * PSE;
       }
+      arow += HWp * PSE;
     }
   }
   // ---- epilogue.  Tiles are either whole image rows (TW == Wo) or a slice of one row (TH == 1), so the tile-local pixel
@@ -968,7 +985,8 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     const bool vec = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
     dim3 grid(tiles_y * tiles_x, N, cdiv(Cstore, 32 * NT));
     // v3 (register prefetch): rows of weights per stage <= 576 (9 chunks/thread), halo <= 448 px (7 chunks/thread)
-    if (vec && halo_cap * 4 <= 7 * 256 && maxkw * 32 * NT <= 576 && !getenv("HDMOE_CONV_V2")) {
+    if (vec && halo_cap * 4 <= 7 * 256 && maxkw * 32 * NT <= 576 && (long)maxkh * maxkw * Cout * Ipad < (1l << 26) &&
+        (long)H * W * Cphys < (1l << 30) && !getenv("HDMOE_CONV_V2")) {
       int tg = 576 / (maxkw * 32 * NT);
       if (tg > maxkh) tg = maxkh;
       while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;
