@@ -53,6 +53,39 @@ __global__ void sigmoid_bwd_kernel(T* dx, const T* dy, const T* y, float a, long
   GRID_STRIDE(i, n) { const float s = to_f(y[i]); dx[i] = from_f<T>(to_f(dy[i]) * a * s * (1.f - s)); }
 }
 
+// ---------------------------------------------------------------- counter RNG (Philox4x32-10)
+DEVI void philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
+  uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+}
+DEVI float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.f / 16777216.f); }
+
+// the Philox key is (per-call salt) + (device step counter) * golden ratio: a captured hipGraph replays with fresh randomness
+// because the counter lives in device memory and is advanced by hdmoe_seed_advance once per step
+DEVI void mix_seed(uint32_t& lo, uint32_t& hi, const unsigned long long* seed_dev) {
+  if (seed_dev) {
+    const unsigned long long k = (((unsigned long long)hi << 32) | lo) + (*seed_dev) * 0x9E3779B97F4A7C15ull;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+  }
+}
+__global__ void seed_advance_kernel(unsigned long long* seed_dev) { *seed_dev += 1ull; }
+
+// dropout keep-mask of element i (4 elements share one Philox call): the same (seed, index) gives the same bit in fwd and bwd
+DEVI bool keep_bit(long i, uint32_t seed_lo, uint32_t seed_hi, float p) {
+  uint32_t r[4];
+  const long q = i >> 2;
+  philox((uint32_t)q, (uint32_t)(q >> 32), seed_lo, seed_hi, r);
+  return u01(r[i & 3]) >= p;
+}
+
 // ---------------------------------------------------------------- FiLM + mp_silu   (Unet_block, model_components.py:242-243)
 template <typename T>
 __global__ void film_silu_fwd_kernel(T* out, const T* u, const float* e, long HW, int C, long n) {
@@ -372,24 +405,39 @@ __global__ void mp_silu_bwd_vec_kernel(T* dx, const T* dy, const T* x, long nv) 
   }
 }
 template <typename T>
-__global__ void film_silu_fwd_vec_kernel(T* out, const T* u, const float* e, long HW, int C, long nv) {
+__global__ void film_silu_fwd_vec_kernel(T* out, const T* u, const float* e, long HW, int C, long nv, uint32_t seed_lo, uint32_t seed_hi,
+                                         const unsigned long long* seed_dev, float p) {
   constexpr int W = VT<T>::W;
   const int cv = C / W;
+  if (p > 0.f) mix_seed(seed_lo, seed_hi, seed_dev);
+  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
   GRID_STRIDE(v, nv) {
     const long row = v / cv; const int c0 = (int)(v - row * cv) * W;
     const float* ep = e + (row / HW) * C + c0;
     float f[W];
     vload<T>(f, u + v * W);
+    uint32_t r4[W];
+    if (p > 0.f) {                                           // F.dropout fused (model_components.py:245-246): W = 4 or 8 elements
 #pragma unroll
-    for (int j = 0; j < W; ++j) f[j] = mp_silu_f(f[j] * ep[j]);
+      for (int q = 0; q < W / 4; ++q) { const long qi = (v * W) / 4 + q; philox((uint32_t)qi, (uint32_t)(qi >> 32), seed_lo, seed_hi, r4 + 4 * q); }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      float a = mp_silu_f(f[j] * ep[j]);
+      if (p > 0.f) a = u01(r4[j]) >= p ? a * inv : 0.f;
+      f[j] = a;
+    }
     vstore<T>(out + v * W, f);
   }
 }
 // block = (pixel chunk, sample); a thread's vectors all carry the same channel chunk (256 % (C/W) == 0): register partials
 template <typename T>
-__global__ __launch_bounds__(256) void film_silu_bwd_vec_kernel(T* du, float* de, const T* da, const T* u, const float* e, long HW, int C, int chunk) {
+__global__ __launch_bounds__(256) void film_silu_bwd_vec_kernel(T* du, float* de, const T* da, const T* u, const float* e, long HW, int C, int chunk,
+                                                               uint32_t seed_lo, uint32_t seed_hi, const unsigned long long* seed_dev, float p) {
   constexpr int W = VT<T>::W;
   extern __shared__ float sm[];
+  if (p > 0.f) mix_seed(seed_lo, seed_hi, seed_dev);
+  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const int s = blockIdx.y, cv = C / W;
   for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = 0.f;
   __syncthreads();
@@ -403,6 +451,13 @@ __global__ __launch_bounds__(256) void film_silu_bwd_vec_kernel(T* du, float* de
   for (long v = p0 * cv + threadIdx.x; v < p1 * cv; v += 256) {
     float uv[W], g[W];
     vload<T>(uv, u + base + v * W); vload<T>(g, da + base + v * W);
+    if (p > 0.f) {
+      uint32_t r4[W];
+#pragma unroll
+      for (int q = 0; q < W / 4; ++q) { const long qi = (base + v * W) / 4 + q; philox((uint32_t)qi, (uint32_t)(qi >> 32), seed_lo, seed_hi, r4 + 4 * q); }
+#pragma unroll
+      for (int j = 0; j < W; ++j) g[j] = u01(r4[j]) >= p ? g[j] * inv : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       g[j] *= mp_silu_grad_f(uv[j] * ev[j]);
@@ -512,32 +567,7 @@ __global__ void take_col_pos_bwd_kernel(float* dw, const float* g, const float* 
   GRID_STRIDE(b, B) { if (w[b * E + e] > 0.f) dw[b * E + e] = g[b]; }
 }
 
-// ---------------------------------------------------------------- counter RNG (Philox4x32-10)
-DEVI void philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
-  uint32_t c[4] = {c0, c1, 0u, 0u};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
-}
-DEVI float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.f / 16777216.f); }
-
 // F.dropout(p): keep with prob 1-p, scale 1/(1-p); the mask is regenerated from (seed, element index) in bwd
-// the Philox key is (per-call salt) + (device step counter) * golden ratio: a captured hipGraph replays with fresh randomness
-// because the counter lives in device memory and is advanced by hdmoe_seed_advance once per step
-DEVI void mix_seed(uint32_t& lo, uint32_t& hi, const unsigned long long* seed_dev) {
-  if (seed_dev) {
-    const unsigned long long k = (((unsigned long long)hi << 32) | lo) + (*seed_dev) * 0x9E3779B97F4A7C15ull;
-    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
-  }
-}
-__global__ void seed_advance_kernel(unsigned long long* seed_dev) { *seed_dev += 1ull; }
-
 template <typename T>
 __global__ void dropout_kernel(T* out, const T* x, uint32_t seed_lo, uint32_t seed_hi, const unsigned long long* seed_dev, float p, long n) {
   mix_seed(seed_lo, seed_hi, seed_dev);
@@ -611,8 +641,27 @@ int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, 
 }
 int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, hipStream_t stream) {
   const long n = (long)N * HW * C;
-  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(u)) L1D(film_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)u, e, HW, C, n / VT<T>::W);
+  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(u)) L1D(film_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)u, e, HW, C, n / VT<T>::W, 0u, 0u, nullptr, 0.f);
                    else L1D(film_silu_fwd_kernel<T>, n, (T*)out, (const T*)u, e, HW, C, n))
+}
+// FiLM + mp_silu + F.dropout in one pass (vectorised layouts only: C % (16/sizeof(T)) == 0)
+int hdmoe_film_silu_drop_fwd(void* out, const void* u, const float* e, int N, long HW, int C, unsigned long long seed,
+                             const unsigned long long* seed_dev, float p, int dtype, hipStream_t stream) {
+  const long n = (long)N * HW * C;
+  if (p < 0.f || p >= 1.f) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(u)) L1D(film_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)u, e, HW, C, n / VT<T>::W,
+                                                                     (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, p);
+                   else return HDMOE_EINVAL)
+}
+int hdmoe_film_silu_drop_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
+                             unsigned long long seed, const unsigned long long* seed_dev, float p, int dtype, hipStream_t stream) {
+  if (N > 65535 || p < 0.f || p >= 1.f) return HDMOE_EINVAL;
+  const int chunk = 256;
+  dim3 grid(cdiv(HW, chunk), N);
+  DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(du) && al16(da) && al16(u))
+                     hipLaunchKernelGGL(film_silu_bwd_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de, (const T*)da, (const T*)u, e, HW, C, chunk,
+                                        (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, p);
+                   else return HDMOE_EINVAL)
 }
 int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
                         int dtype, hipStream_t stream) {
@@ -620,7 +669,7 @@ int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, cons
   const int chunk = 256;
   dim3 grid(cdiv(HW, chunk), N);
   DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(du) && al16(da) && al16(u))
-                     hipLaunchKernelGGL(film_silu_bwd_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de, (const T*)da, (const T*)u, e, HW, C, chunk);
+                     hipLaunchKernelGGL(film_silu_bwd_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de, (const T*)da, (const T*)u, e, HW, C, chunk, 0u, 0u, nullptr, 0.f);
                    else hipLaunchKernelGGL(film_silu_bwd_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, (T*)du, de,
                                       (const T*)da, (const T*)u, e, HW, C, chunk))
 }

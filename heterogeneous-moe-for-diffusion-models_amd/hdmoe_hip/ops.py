@@ -456,30 +456,44 @@ def sigmoid(x: Tensor, a: float = 1.0) -> Tensor:
 
 class _FilmSiluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, e):
+    def forward(ctx, u, e, p, seed):
         u = _c(u); e = _f32(e)
         N, C = u.shape[0], u.shape[-1]
         HW = u.numel() // (N * C)
         out = torch.empty_like(u)
-        call("hdmoe_film_silu_fwd", out, u, e, N, HW, C, _dt(u))
+        if p > 0.0:
+            call("hdmoe_film_silu_drop_fwd", out, u, e, N, HW, C, seed, step_counter(u.device), p, _dt(u))
+        else:
+            call("hdmoe_film_silu_fwd", out, u, e, N, HW, C, _dt(u))
         ctx.save_for_backward(u, e)
+        ctx.meta = (p, seed)
         return out
 
     @staticmethod
     def backward(ctx, g):
         u, e = ctx.saved_tensors
+        p, seed = ctx.meta
         g = _c(g)
         N, C = u.shape[0], u.shape[-1]
         HW = u.numel() // (N * C)
         du = torch.empty_like(u)
         de = torch.zeros_like(e)
-        call("hdmoe_film_silu_bwd", du, de, g, u, e, N, HW, C, _dt(u))
-        return du, de
+        if p > 0.0:
+            call("hdmoe_film_silu_drop_bwd", du, de, g, u, e, N, HW, C, seed, step_counter(u.device), p, _dt(u))
+        else:
+            call("hdmoe_film_silu_bwd", du, de, g, u, e, N, HW, C, _dt(u))
+        return du, de, None, None
 
 
-def film_silu(u: Tensor, e: Tensor) -> Tensor:
-    """mp_silu(u * e[n, c]) with e a float32 (N, C) embedding (model_components.py:242-243)."""
-    return _FilmSiluFn.apply(u, e)
+def film_silu(u: Tensor, e: Tensor, p: float = 0.0, training: bool = False) -> Tensor:
+    """dropout_p(mp_silu(u * e[n, c])) with e a float32 (N, C) embedding (model_components.py:242-246); the dropout is fused
+    into the same pass when the layout is 16-byte vectorisable, otherwise it runs as a separate kernel."""
+    p = float(p) if training else 0.0
+    C = u.shape[-1]
+    vw = 16 // u.element_size()
+    if p > 0.0 and not (C % vw == 0 and 256 % (C // vw) == 0):
+        return dropout(_FilmSiluFn.apply(u, e, 0.0, 0), p, True)
+    return _FilmSiluFn.apply(u, e, p, _next_seed() if p > 0.0 else 0)
 
 
 class _ScaleRowsFn(torch.autograd.Function):

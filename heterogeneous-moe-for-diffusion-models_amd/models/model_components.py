@@ -125,8 +125,7 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
     else:
         h = ops.mp_silu(x)
     y = conv("conv_res1", h, b0.conv_gain1)
-    y = ops.film_silu(y, emb)
-    y = ops.dropout(y, b0.dropout, tr and b0.dropout != 0)
+    y = ops.film_silu(y, emb, b0.dropout, tr)                 # FiLM * emb -> mp_silu -> F.dropout, one pass
     if b0.type == "dec" and b0.conv_skip is not None:
         x = conv("conv_skip", x)
     # conv_res2 with mp_sum(x, main, residual_balance) fused into its epilogue

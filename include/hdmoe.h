@@ -84,6 +84,10 @@ int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, 
 int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, HS stream);  /* mp_silu(u * e[n][c]) */
 int hdmoe_film_silu_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
                         int dtype, HS stream);                                                                   /* de accumulates */
+int hdmoe_film_silu_drop_fwd(void* out, const void* u, const float* e, int N, long HW, int C, unsigned long long seed,
+                             const unsigned long long* seed_dev, float p, int dtype, HS stream);                  /* + F.dropout fused (:245-246) */
+int hdmoe_film_silu_drop_bwd(void* du, float* de, const void* da, const void* u, const float* e, int N, long HW, int C,
+                             unsigned long long seed, const unsigned long long* seed_dev, float p, int dtype, HS stream);
 int hdmoe_scale_rows_fwd(void* out, const void* x, const float* s, long rows, long L, int dtype, HS stream);    /* out[r][:] = s[r]*x[r][:] */
 int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, const float* s, long rows, long L,
                          int dtype, HS stream);                                                                  /* dx and/or ds (accumulates) */

@@ -623,3 +623,20 @@ def test_sampler_runs_on_the_real_model(golden_full):
     sg = EDM_Sampler(model, model, num_solve_steps=4, use_graph=True)
     outg = sg.sample(noise, dev(g["text"][:2]), -1.2, 1.6)
     close_scaled(outg, out, 1e-5, msg="graph replay vs eager")
+
+
+def test_fused_film_dropout_consistency():
+    """FiLM + mp_silu + dropout in one pass: keep-rate, scaling, and the backward uses exactly the forward's mask."""
+    from hdmoe_hip import ops
+    ops.manual_seed(3)
+    u = torch.randn(4, 32, 32, 64, device=DEV).bfloat16().requires_grad_(True)
+    e = (1 + 0.1 * torch.randn(4, 64, device=DEV)).requires_grad_(True)
+    ref = ops.film_silu(u.detach(), e.detach())                      # no dropout
+    y = ops.film_silu(u, e, 0.2, True)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.8) < 1e-2
+    close_scaled(y[kept].float(), (ref[kept].float() / 0.8), 1e-2, msg="kept values are ref / (1-p)")
+    y.float().sum().backward()
+    g_ref = torch.autograd.grad(ops.film_silu(u, e).float().sum(), u)[0]
+    assert float(u.grad[~kept].float().abs().max()) == 0.0            # dropped positions get no gradient
+    close_scaled(u.grad[kept].float(), g_ref[kept].float() / 0.8, 2e-2, msg="masked gradient")
