@@ -19,10 +19,11 @@ MAX_GROUPS = 8
 
 # one letter per argument:
 #   p device pointer (tensor / None)      P host array of device pointers (list of tensors / None entries)
-#   I host int array (list of ints)       i int   l long   f float   u unsigned long long   s stream
+#   I host int array (list of ints)       F host float array     i int   l long   f float   u unsigned long long   s stream
 # The table is derived from include/hdmoe.h itself, so the binding cannot drift from the declared C ABI.
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "hdmoe.h"))
 _HOST_INT_ARRAYS = {"kh", "kw", "pt", "pl"}
+_HOST_FLOAT_ARRAYS = {"group_lr", "group_wd"}
 
 
 def _parse_header(path: str) -> dict:
@@ -44,7 +45,7 @@ def _parse_header(path: str) -> dict:
             elif "* const*" in a or "*const*" in a:
                 code += "P"
             elif "*" in a:
-                code += "I" if pname in _HOST_INT_ARRAYS else "p"
+                code += "I" if pname in _HOST_INT_ARRAYS else ("F" if pname in _HOST_FLOAT_ARRAYS else "p")
             elif a.startswith("unsigned long long"):
                 code += "u"
             elif a.startswith("long"):
@@ -61,7 +62,7 @@ def _parse_header(path: str) -> dict:
 
 SIGNATURES = _parse_header(HEADER_PATH)
 
-_CT = {"p": ctypes.c_void_p, "P": ctypes.c_void_p, "I": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long,
+_CT = {"p": ctypes.c_void_p, "P": ctypes.c_void_p, "I": ctypes.c_void_p, "F": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long,
        "f": ctypes.c_float, "u": ctypes.c_ulonglong, "s": ctypes.c_void_p}
 
 _lib = None
@@ -131,6 +132,8 @@ def call(name: str, *args):
             arr = _ptr_array(a); keep.append(arr); conv.append(ctypes.cast(arr, ctypes.c_void_p) if arr is not None else None)
         elif c == "I":
             arr = _int_array(a); keep.append(arr); conv.append(ctypes.cast(arr, ctypes.c_void_p))
+        elif c == "F":
+            arr = (ctypes.c_float * len(a))(*[float(v) for v in a]); keep.append(arr); conv.append(ctypes.cast(arr, ctypes.c_void_p))
         elif c == "f":
             conv.append(float(a))
         else:

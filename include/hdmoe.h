@@ -169,6 +169,15 @@ int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU
                        const float* sse, const float* denoised, const float* target, const float* log_var, const float* rU,
                        const float* rV, int B, long L, int E, float unet_bal, float vit_bal, float z_bal, HS stream);
 
+/* ---- N3: fused multi-tensor clip_grad_norm_ + AdamW  (Utils/training.py:55-65,195-197) ----------------------------------- */
+/* descs: device array of {p, g, m, v addresses, numel, group} (hdmoe_opt_desc_bytes() bytes each); chunks: device int32 pairs
+ * (descriptor index, 4096-element chunk index).  The clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) is read on the device. */
+int hdmoe_opt_desc_bytes(void);
+int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, HS stream);
+int hdmoe_mt_clip_scale(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, HS stream);
+int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, const float* group_lr,
+                   const float* group_wd, int ngroups, float beta1, float beta2, float eps, int step, HS stream);
+
 #undef HS
 #ifdef __cplusplus
 }

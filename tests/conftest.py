@@ -31,3 +31,24 @@ def golden_components():
 def golden_full(request):
     import torch
     return torch.load(os.path.join(GOLDEN, f"full_config{request.param}.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session", params=[2, 3, 4])
+def golden_wide(request):
+    """BASELINE configs 2-4 at their real widths: outputs of the reference under oracle/recipe.py's weights/inputs."""
+    import torch
+    return torch.load(os.path.join(GOLDEN, f"wide_config{request.param}.pt"), weights_only=False)
+
+
+def wide_setup(g):
+    """(model class, constructor kwargs, recipe state_dict, recipe inputs) of a wide fixture; modules built on CPU."""
+    from Utils import configs
+    from models import model_config1, model_config2
+    from oracle.recipe import fill_state, make_inputs
+    bc = configs.BASELINE_CONFIGS[g["cfg_id"]]
+    kw = configs.model_kwargs(**bc["over"])
+    cls = (model_config1 if bc["module"] == 1 else model_config2).preconditioned_HDMOEM
+    model = cls(**kw)
+    state = fill_state(model.state_dict(), g["seed"])
+    inp = make_inputs(g["B"], kw["IN_in_channels"], kw["IN_img_resolution"], kw["num_experts"], 77, kw["text_emb_dim"], g["seed"])
+    return bc["module"], model, kw, state, inp

@@ -388,6 +388,48 @@ def test_full_model_edge_cases(golden_full):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def _run_wide(g, dtype):
+    import hdmoe_hip
+    from conftest import wide_setup
+    hdmoe_hip.set_compute_dtype(dtype)
+    variant, model, kw, state, inp = wide_setup(g)
+    model = load_into(model, state)
+    x = dev(inp["x"]).requires_grad_(True)
+    out = model(x=x, sigma=dev(inp["sigma"]), text_emb=dev(inp["text"]), Unet_router_mask=dev(inp["unet_mask"]),
+                Vit_router_mask=dev(inp["vit_mask"]), zeta=0.0, return_log_var=True, **g["extra"])
+    return model, kw, inp, x, out
+
+
+@pytest.mark.parametrize("dtype,rel_out,rel_grad", [(torch.float32, 1e-4, 3e-4), (torch.bfloat16, 3e-2, 6e-2)])
+def test_full_model_real_widths(golden_wide, dtype, rel_out, rel_grad):
+    """BASELINE configs 2 / 3 / 4 at their real widths (cfg32; 8 experts with 7x7 kernels; R = 64; text 77 x 768) against
+    the reference's own outputs for oracle/recipe.py's weights: router indices exact, outputs / loss / gradients in tolerance.
+    Measured fp32 error is <= 3e-5 of each tensor's max.  The fixture seeds are chosen so that no GroupNorm+ReLU pre-activation
+    of the router trunks sits within fp32 rounding of zero: one such element flips its ReLU mask between summation orders and
+    moves the trunk gradients by ~1e-2 (tools/router_err.py shows the mechanism); that is conditioning of the reference's
+    own function, not a kernel property."""
+    import hdmoe_hip
+    from Utils.utils import EDM_LOSS
+    g = golden_wide
+    model, kw, inp, x, out = _run_wide(g, dtype)
+    k = kw["top_k"]
+    for key in ("Unet_raw", "vit_raw"):                # routers run fp32 in both modes
+        assert torch.equal(torch.topk(out[key].detach().cpu(), k, dim=-1).indices, g["topk_idx"][key]), key
+        close_scaled(out[key], g["out"][key], 1e-3, msg=key)
+    for key, ref in g["out"].items():          # out_gate = per-pixel softmax of gate logits built on bf16 features: 2x the slack
+        close_scaled(out[key], ref, rel_out * (2 if key == "out_gate" and dtype == torch.bfloat16 else 1), msg=key)
+    lc = g["loss_cfg"]
+    crit = EDM_LOSS(num_experts=kw["num_experts"], sigma_data=0.5, Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"], z_bal=lc["z_bal"], prior_bal=0.0)
+    loss = crit(sigma_vec=dev(inp["sigma"]), x=dev(inp["x0"]), sigma=dev(inp["sigma"]), out_model=out)
+    close(loss["loss"], g["loss"]["loss"], rtol=10 * rel_out, atol=1e-4, msg="loss")
+    loss["loss"].backward()
+    close_scaled(x.grad, g["x_grad"], rel_grad, msg="x_grad")
+    pg = pgrads(model)
+    for n, gref in g["param_grads"].items():
+        close_scaled(pg[n], gref, rel_grad, msg=n)
+    hdmoe_hip.set_compute_dtype(torch.float32)
+
+
 # ----------------------------------------------------------------------------------------------- ops vs oracle at larger shapes
 @pytest.mark.parametrize("dtype,rel", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, 32), (64, 32, 5, 16), (96, 64, 3, 16), (32, 4, 3, 32), (128, 128, 1, 8),
@@ -640,3 +682,88 @@ def test_fused_film_dropout_consistency():
     g_ref = torch.autograd.grad(ops.film_silu(u, e).float().sum(), u)[0]
     assert float(u.grad[~kept].float().abs().max()) == 0.0            # dropped positions get no gradient
     close_scaled(u.grad[kept].float(), g_ref[kept].float() / 0.8, 2e-2, msg="masked gradient")
+
+
+# ----------------------------------------------------------------------------------------------- N3: fused clip + AdamW
+def test_fused_adamw_and_clip_match_torch():
+    from hdmoe_hip.optim import FusedAdamW, clip_grad_norm_
+    torch.manual_seed(0)
+    shapes = [(33, 7, 3, 3), (5000,), (64, 64), (), (4097,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    dev_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    groups = lambda ps: [{"params": ps[:2], "lr": 5e-3}, {"params": ps[2:], "lr": 2e-2, "weight_decay": 0.1}]
+    ref_o = torch.optim.AdamW(groups(ref_p))
+    dev_o = FusedAdamW(groups(dev_p))
+    sched_r = torch.optim.lr_scheduler.CosineAnnealingLR(ref_o, T_max=10, eta_min=1e-5)
+    sched_d = torch.optim.lr_scheduler.CosineAnnealingLR(dev_o, T_max=10, eta_min=1e-5)
+    for it in range(4):
+        for rp, dp in zip(ref_p, dev_p):
+            g = torch.randn(rp.shape) * (3.0 if it % 2 == 0 else 0.01)      # clipped on even steps only
+            rp.grad, dp.grad = g.clone(), g.clone().to(DEV)
+        if it < 2:                                                            # two-call form (drop-in for the reference loop)
+            nr = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+            nd = clip_grad_norm_(dev_p, 1.0)
+            close(nd, nr, rtol=1e-5)
+            for rp, dp in zip(ref_p, dev_p):
+                close(dp.grad, rp.grad, rtol=1e-5, atol=1e-7)
+            dev_o.step()
+        else:                                                                 # fused form: clip coefficient applied inside the update
+            torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+            dev_o.step(clip=(dev_p, 1.0))
+        ref_o.step(); sched_r.step(); sched_d.step()
+        for rp, dp in zip(ref_p, dev_p):
+            close(dp, rp, rtol=2e-5, atol=1e-6, msg=f"param after step {it}")
+    sd = dev_o.state_dict()                                                   # torch.optim.AdamW-compatible checkpoint layout
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["param_groups"]) == 2
+    torch.optim.AdamW(groups([torch.nn.Parameter(p.detach().clone()) for p in dev_p])).load_state_dict(sd)
+    close(sd["state"][1]["exp_avg_sq"], ref_o.state_dict()["state"][1]["exp_avg_sq"], rtol=1e-4, atol=1e-8)
+
+
+def test_trainer_iteration_and_checkpoint_roundtrip(tmp_path):
+    """Reference training.py:110-197 iteration order on the HIP path + the checkpoint dictionary of :242-271: the file
+    restores model and optimizer exactly, and its optimizer state also loads into torch.optim.AdamW (reference optimizer)."""
+    import hdmoe_hip
+    from Utils import configs, training
+    from models import model_config2
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    over = dict(img_resolution=16, internal_channels=8, time_emb_dim=16, text_emb_dim=32, VIT_num_blocks=1, VIT_patch_sizes=[2, 4, 4, 8],
+                VIT_num_groups=2, VIT_num_heads=2, VIT_emb_size=8, Unet_num_blocks=1, Unet_model_channels=8, log_var_channels=8, top_k=2)
+    mcfg = dict(configs.model_configs, **over, total_steps=10, save_dir=str(tmp_path))
+    torch.manual_seed(0)
+    model = model_config2.preconditioned_HDMOEM(**configs.model_kwargs(mcfg)).to(DEV)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("out_gain"):
+                p.fill_(0.5)
+    tr = training.Trainer(model, mcfg, configs.optim_configs, configs.loss_configs, configs.mask_configs, configs.zeta_configs)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    batches = [(0.5 * torch.randn(6, 4, 16, 16, device=DEV, generator=gen), torch.randn(6, 5, 32, device=DEV, generator=gen)) for _ in range(3)]
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    seen = []
+    training.train_steps(tr, batches, on_step=lambda s, r: seen.append(float(r["loss"]["loss"])))
+    assert len(seen) == 3 and all(math.isfinite(v) for v in seen)
+    moved = [n for n, p in model.named_parameters() if not torch.equal(p, before[n])]
+    assert any("Unet_experts" in n for n in moved) and any("vit_router" in n for n in moved)
+    assert abs(tr.optimizer.param_groups[1]["lr"] - configs.optim_configs["lr_vit"]) < 1e-3 * configs.optim_configs["lr_vit"]
+    path = training.save_checkpoint(model, tr.optimizer, 3, seen[-1], {"model_configs": mcfg}, "ckpt_3.pt")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"step", "model_state_dict", "optimizer_state_dict", "mse", "config"}
+    model2 = model_config2.preconditioned_HDMOEM(**configs.model_kwargs(mcfg)).to(DEV)
+    opt2 = training.build_optimizer(model2, configs.optim_configs)
+    training.load_checkpoint(path, model2, opt2, map_location=DEV)
+    for (n, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), n
+    s1, s2 = tr.optimizer.state_dict(), opt2.state_dict()
+    assert s1["param_groups"] == s2["param_groups"]
+    for k in s1["state"]:
+        for f in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(s1["state"][k][f].cpu(), s2["state"][k][f].cpu()), (k, f)
+    ref_opt = torch.optim.AdamW([{"params": [torch.nn.Parameter(p.detach().cpu().clone()) for p in g["params"]], "lr": g["lr"]}
+                                 for g in opt2.param_groups])
+    ref_opt.load_state_dict(ck["optimizer_state_dict"])            # the reference's optimizer accepts the file
+    # resumed optimizer keeps stepping from the stored step count
+    for p in model2.parameters():
+        p.grad = torch.zeros_like(p)
+    opt2.step()
+    assert int(next(iter(opt2.state.values()))["step"]) == 4
+    hdmoe_hip.set_compute_dtype(torch.float32)

@@ -63,3 +63,27 @@ def test_constructor_signatures_match_reference_positional_use():
     assert vb.skip_proj is None and mc.Vit_block(2, 2, 6, 9, 8).skip_proj is not None
     at = mi.MP_Attention(2, 8, 9, is_cross_attn=True)
     assert at.rel_pos_bias is None and at.q_time is None and at.k_time is None
+
+
+def test_checkpoint_dictionary_layout(tmp_path):
+    """save_checkpoint writes the reference's dictionary (training.py:262-268) and the optimizer groups follow :55-60."""
+    import torch
+    from Utils import configs, training
+    from models import model_config2
+    over = dict(img_resolution=16, internal_channels=8, time_emb_dim=16, text_emb_dim=32, VIT_num_blocks=1, VIT_patch_sizes=[2, 4, 4, 8],
+                VIT_num_groups=2, VIT_num_heads=2, VIT_emb_size=8, Unet_num_blocks=1, Unet_model_channels=8, log_var_channels=8)
+    mcfg = dict(configs.model_configs, **over, save_dir=str(tmp_path))
+    model = model_config2.preconditioned_HDMOEM(**configs.model_kwargs(mcfg))
+    opt = training.build_optimizer(model, configs.optim_configs)
+    assert [g["lr"] for g in opt.param_groups] == [configs.optim_configs[k] for k in ("lr_unet", "lr_vit", "lr_attn", "lr_router")]
+    n_opt = sum(p.numel() for g in opt.param_groups for p in g["params"])
+    n_exp = sum(p.numel() for m in (model.net.Unet_experts, model.net.VIT_experts, model.net.cross_attn, model.net.Unet_router,
+                                    model.net.vit_router) for p in m.parameters())
+    assert n_opt == n_exp
+    path = training.save_checkpoint(model, opt, 7, 0.25, {"model_configs": mcfg}, "ckpt_7.pt")
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"step", "model_state_dict", "optimizer_state_dict", "mse", "config"} and ck["step"] == 7
+    assert list(ck["model_state_dict"]) == list(model.state_dict())
+    model2 = model_config2.preconditioned_HDMOEM(**configs.model_kwargs(mcfg))
+    training.load_checkpoint(path, model2, training.build_optimizer(model2, configs.optim_configs))
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))

@@ -169,3 +169,27 @@ def test_full_model(golden_full):
             assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0
         else:
             close(P[n].grad, gref, rtol=1e-3, atol=1e-6)
+
+
+def test_full_model_real_widths(golden_wide):
+    """BASELINE configs 2 / 3 / 4 at cfg32 widths (4 and 8 heterogeneous experts incl. 7x7, R = 32 and 64, text 77x768):
+    the oracle against the reference's outputs for the same recipe weights."""
+    from conftest import wide_setup
+    g = golden_wide
+    variant, _, kw, state, inp = wide_setup(g)
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in state.items()}
+    x = inp["x"].clone().requires_grad_(True)
+    out = O.preconditioned_hdmoem(P, kw, variant, x, inp["sigma"], inp["text"], inp["unet_mask"], inp["vit_mask"],
+                                  return_log_var=True, **g["extra"])
+    k = kw["top_k"]
+    for key in ("Unet_raw", "vit_raw"):
+        assert torch.equal(torch.topk(out[key], k, dim=-1).indices, g["topk_idx"][key])
+    for key, ref in g["out"].items():
+        close(out[key], ref, rtol=1e-4, atol=2e-5)
+    lc = g["loss_cfg"]
+    loss = O.edm_loss(out, inp["x0"], kw["num_experts"], lc["unet_bal"], lc["vit_bal"], lc["z_bal"])
+    close(loss["loss"], g["loss"]["loss"], rtol=1e-5, atol=1e-6)
+    loss["loss"].backward()
+    close_scaled(x.grad, g["x_grad"], 1e-4)
+    for n, gref in g["param_grads"].items():
+        close_scaled(P[n].grad, gref, 1e-4)
