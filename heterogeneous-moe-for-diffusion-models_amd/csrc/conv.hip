@@ -538,6 +538,224 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
   }
 }
 
+// ------------------------------------------------------------------ conv forward / dgrad v5: lean staging + vector epilogue
+// Same tile and stage walk as v3.  What changed, and why (PMC on 64->64 3x3 bf16: v3 executed ~15 VALU instructions per MFMA,
+// a plain VALU instruction issues at 4 cycles per wave, so the vector pipe -- not the matrix pipe -- set the pace):
+//   * MFMA operand roles are swapped (A = weights, B = activations): an accumulator lane then owns ONE pixel and four
+//     consecutive channels per register quad, so the epilogue is one 8-byte (bf16) / 16-byte (f32) store per quad instead
+//     of sixteen 2-byte stores with a bounds test and a 64-bit address each;
+//   * weight staging needs no per-thread plan: with 32*NT rows per tap the (tap, channel-row, piece) of a thread's k-th
+//     16-byte piece are compile-time functions of k; rows past Cout / taps past the stage are clamped to valid addresses
+//     (their products are never stored) instead of branching;
+//   * layers with a channel tail or the implicit ones channel stay on v3 (Cphys % (16/sizeof T) == 0 and !ones here), which
+//     removes the scalar tail path from the hot kernel.
+template <typename T> struct Quad;
+template <> struct Quad<bf16> { typedef bf16x4 type; };
+template <> struct Quad<float> { typedef f32x4 type; };
+
+template <typename T, int NT, bool LEPI>
+__global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg) {
+  constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16;
+  constexpr int NB = 32 * NT, LNB = NT == 1 ? 5 : (NT == 2 ? 6 : 7);
+  constexpr int NWR = 9, NHR = 7;                           // 16-B pieces per thread held in registers (weights / halo)
+  typedef typename Quad<T>::type QT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sA = reinterpret_cast<T*>(smem_raw);                    // [halo px][PSE]
+  T* sB = sA + (long)halo_cap * PSE;                         // [tg*kw][NB][PSE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int g = find_group(a.seg, a.ngroups, n);
+  if (g < 0) return;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int nbase = blockIdx.z * NB;
+  const int kh = a.kh[g], kw = a.kw[g], pt = a.pt[g], pl = a.pl[g];
+  const int HWp = TW + kw - 1, HHp = TH + kh - 1;
+  const int npx = TH * TW;
+  const int nhal = HHp * HWp * 4;
+  const int magic_hw = (1 << 20) / HWp + 1;
+  const T* x = (const T*)a.x + (long)n * a.H * a.W * a.Cphys;
+  const T* w = (const T*)a.w + (long)g * a.wstride;
+
+  int abase[CV2_MT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m) {
+    const int q = wave * (32 * CV2_MT) + m * 32 + r;
+    const int qc = q < npx ? q : npx - 1;
+    const int ty = qc / TW, tx = qc - ty * TW;
+    abase[m] = (ty * HWp + tx) * PSE + 8 * h;
+  }
+  f32x16 acc[CV2_MT][NT];
+#pragma unroll
+  for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[m][b] = (f32x16)(0.f);
+
+  const int spc = (kh + tg - 1) / tg;                        // stages per channel chunk
+  const int nstages = ((a.Ipad + KC - 1) / KC) * spc;
+  const int ntaps = kh * kw;
+  const int wrows = tg * kw * NB;                            // LDS weight rows of a full stage
+  // halo plan (per tile): global offset at channel 0 / LDS offset of this thread's pieces
+  uint4 rw[NWR], rh[NHR];
+  int hoff[NHR], hlds[NHR];
+#pragma unroll
+  for (int k = 0; k < NHR; ++k) {
+    const int e = tid + k * 256;
+    const int px = e >> 2, cc = (e & 3) * VW;
+    const int hy = (int)(((unsigned)px * (unsigned)magic_hw) >> 20), hx = px - hy * HWp;
+    const int iy = ty0 + hy - pt, ix = tx0 + hx - pl;
+    const bool inb = e < nhal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    hoff[k] = inb ? (iy * a.W + ix) * a.Cphys + cc : -1;
+    hlds[k] = (e < nhal) ? px * PSE + cc : -1;
+  }
+  // weight pieces: row = (tid >> 2) + 64 k, piece = tid & 3  ->  co = row & (NB-1), local tap = row >> LNB
+  const int wcc = (tid & 3) * VW;
+  const int wrow0 = tid >> 2;
+  const long wtap = (long)a.Cout * a.Ipad;
+  auto prefetch = [&](int st) {
+    const int c0 = (st / spc) * KC, ky0 = (st % spc) * tg;
+    const int chw = min(c0 + wcc, a.Ipad - VW);              // a piece past the padded row reads valid bytes (unused k-steps)
+    const int tap0 = ky0 * kw;
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k * 64 < wrows) {                                  // uniform
+        const int row = wrow0 + 64 * k;
+        const int co = min(nbase + (row & (NB - 1)), a.Cout - 1);
+        const int tap = min(tap0 + (row >> LNB), ntaps - 1);
+        v = *reinterpret_cast<const uint4*>(w + tap * wtap + (long)co * a.Ipad + chw);
+      }
+      rw[k] = v;
+    }
+    if (ky0 == 0) {
+#pragma unroll
+      for (int k = 0; k < NHR; ++k) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (hoff[k] >= 0 && c0 + (((tid + k * 256) & 3) * VW) < a.Cphys) v = *reinterpret_cast<const uint4*>(x + hoff[k] + c0);
+        rh[k] = v;
+      }
+    }
+  };
+
+  prefetch(0);
+  for (int st = 0; st < nstages; ++st) {
+    const int c0 = (st / spc) * KC, ky0 = (st % spc) * tg;
+    const int tgr = min(tg, kh - ky0);
+    const int ksteps = min(KS, (a.Ipad - c0) >> 4);
+    __syncthreads();                                         // readers of the previous stage are done
+#pragma unroll
+    for (int k = 0; k < NWR; ++k)
+      if (wrow0 + 64 * k < wrows) *reinterpret_cast<uint4*>(sB + (wrow0 + 64 * k) * PSE + wcc) = rw[k];
+    if (ky0 == 0) {
+#pragma unroll
+      for (int k = 0; k < NHR; ++k)
+        if (hlds[k] >= 0) *reinterpret_cast<uint4*>(sA + hlds[k]) = rh[k];
+    }
+    __syncthreads();
+    if (st + 1 < nstages) prefetch(st + 1);
+    const T* arow = sA + ky0 * HWp * PSE;
+    const T* bt = sB + r * PSE + 8 * h;
+    for (int kyl = 0; kyl < tgr; ++kyl) {
+      const T* ap = arow;
+      for (int kx = 0; kx < kw; ++kx) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+          if (s2 >= ksteps) break;
+          Frag8<T> fx[CV2_MT], fw[NT];
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m) load8(fx[m], ap + abase[m] + 16 * s2);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) load8(fw[b], bt + b * 32 * PSE + 16 * s2);
+#pragma unroll
+          for (int m = 0; m < CV2_MT; ++m)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) mma32(acc[m][b], fw[b], fx[m]);       // rows = channels, columns = pixels
+        }
+        ap += PSE;
+        bt += NB * PSE;
+      }
+      arow += HWp * PSE;
+    }
+  }
+  // ---- epilogue: lane = pixel (32m + r of the wave's 64), register quad i = channels 32b + 8i + 4h .. +3
+  const long HWo = (long)a.Ho * a.Wo;
+  const long lin0 = (long)ty0 * a.Wo + tx0;
+  T* y = (T*)a.y + (long)n * HWo * a.Cstore;
+  const T* res = a.res ? (const T*)a.res + (long)n * HWo * a.Cstore : nullptr;
+  const int qlim = (TH > 1) ? npx : min(npx, a.Wo - tx0);
+  if constexpr (LEPI) {
+    // Through LDS: a quad store straight from the accumulator layout hands the memory system 32 separate 8/16-byte
+    // pieces per instruction (one per pixel row).  Each wave instead parks its 64 x NB tile in its own LDS slab
+    // [64 px][NB + pad] and streams it out as 16 B per lane, consecutive lanes covering whole pixel rows.
+    constexpr int ROW = NB + VW;                             // elements; +16 B keeps the rows off each other's banks
+    constexpr int PPR = NB / VW;                             // 16-B pieces per pixel row
+    __syncthreads();                                         // every wave is done reading the operand tiles
+    T* sE = reinterpret_cast<T*>(smem_raw) + wave * 64 * ROW;
+#pragma unroll
+    for (int m = 0; m < CV2_MT; ++m) {
+      const int q = wave * (32 * CV2_MT) + m * 32 + r;
+      const long lin = lin0 + q;
+      const bool ok = q < qlim && lin < HWo;
+      const long pix = lin * a.Cstore + nbase + 4 * h;
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cl = 32 * b + 8 * i;
+          float v0 = a.alpha * acc[m][b][4 * i], v1 = a.alpha * acc[m][b][4 * i + 1];
+          float v2 = a.alpha * acc[m][b][4 * i + 2], v3 = a.alpha * acc[m][b][4 * i + 3];
+          if (res && ok && nbase + cl + 4 * h < a.Cstore) {
+            const QT rv = *reinterpret_cast<const QT*>(res + pix + cl);
+            v0 += a.beta * (float)rv[0]; v1 += a.beta * (float)rv[1]; v2 += a.beta * (float)rv[2]; v3 += a.beta * (float)rv[3];
+          }
+          QT o;
+          o[0] = from_f<T>(v0); o[1] = from_f<T>(v1); o[2] = from_f<T>(v2); o[3] = from_f<T>(v3);
+          *reinterpret_cast<QT*>(sE + (32 * m + r) * ROW + cl + 4 * h) = o;
+        }
+    }
+    // the slab is private to the wave: LDS operations of one wave complete in order, no workgroup barrier needed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps the compiler from hoisting the reads over the writes)
+    const int piece = lane % PPR, prow = lane / PPR;
+    const int cch = nbase + piece * VW;
+#pragma unroll
+    for (int j = 0; j < PPR; ++j) {
+      const int pl = j * (64 / PPR) + prow;                  // pixel within the wave's 64
+      const int q = wave * 64 + pl;
+      const long lin = lin0 + q;
+      if (q < qlim && lin < HWo && cch < a.Cstore) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sE + pl * ROW + piece * VW);
+        *reinterpret_cast<uint4*>(y + lin * a.Cstore + cch) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < CV2_MT; ++m) {
+      const int q = wave * (32 * CV2_MT) + m * 32 + r;
+      const long lin = lin0 + q;
+      if (q < qlim && lin < HWo) {
+        const long pix = lin * a.Cstore + nbase + 4 * h;
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cl = 32 * b + 8 * i;                   // + 4h + nbase = first channel of the quad
+            if (nbase + cl + 4 * h < a.Cstore) {
+              float v0 = a.alpha * acc[m][b][4 * i], v1 = a.alpha * acc[m][b][4 * i + 1];
+              float v2 = a.alpha * acc[m][b][4 * i + 2], v3 = a.alpha * acc[m][b][4 * i + 3];
+              if (res) {
+                const QT rv = *reinterpret_cast<const QT*>(res + pix + cl);
+                v0 += a.beta * (float)rv[0]; v1 += a.beta * (float)rv[1]; v2 += a.beta * (float)rv[2]; v3 += a.beta * (float)rv[3];
+              }
+              QT o;
+              o[0] = from_f<T>(v0); o[1] = from_f<T>(v1); o[2] = from_f<T>(v2); o[3] = from_f<T>(v3);
+              *reinterpret_cast<QT*>(y + pix + cl) = o;
+            }
+          }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const void* x;       // [N][H][W][Cphys]
@@ -991,6 +1209,18 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
       if (tg > maxkh) tg = maxkh;
       while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;
       const size_t lds3 = (size_t)80 * (halo_cap + tg * maxkw * 32 * NT);
+      static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
+      const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
+      if (lds3 <= 64 * 1024 && v5ok) {
+        // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 64 px x (32 NT + pad) elements
+        const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 64 * (32 * NT + 16 / esz) * esz <= lds3;
+#define CV5_LAUNCH(TT, NTv)                                                                                                              \
+  do { if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);  \
+       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); } while (0)
+        if (dtype == HDMOE_F32) { if (NT == 1) CV5_LAUNCH(float, 1); else CV5_LAUNCH(float, 2); }
+        else { if (NT == 1) CV5_LAUNCH(bf16, 1); else CV5_LAUNCH(bf16, 2); }
+        return hdmoe_launch_status();
+      }
       if (lds3 <= 64 * 1024) {
         if (dtype == HDMOE_F32) {
           if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<float, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);

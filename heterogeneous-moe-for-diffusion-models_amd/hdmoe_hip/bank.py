@@ -25,6 +25,24 @@ _DESC = np.dtype([("w_raw", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("G", "<u8"), 
 
 ACTIVE: Optional["WeightBank"] = None
 
+# Streams that ran part of the current step beside the caller's stream (models/_assembly.py forks the ViT experts onto side
+# streams).  Their weight-gradient kernels write the bank's slab without handing a gradient to autograd, so nothing makes
+# the engine join them: `_finish` does it explicitly before the one launch that consumes the slab.
+FORKED_STREAMS: list = []
+
+
+def note_forked_streams(streams) -> None:
+    for s in streams:
+        if s not in FORKED_STREAMS:
+            FORKED_STREAMS.append(s)
+
+
+def join_forked_streams() -> None:
+    if FORKED_STREAMS and torch.cuda.is_available():
+        cur = torch.cuda.current_stream()
+        for s in FORKED_STREAMS:
+            cur.wait_stream(s)
+
 
 class Entry:
     __slots__ = ("params", "dtype", "gain", "alpha", "normalize", "O", "I", "khs", "kws", "Ipad", "Opad", "wstride", "wdstride",
@@ -150,6 +168,7 @@ class WeightBank:
         """Call at the start of a top-level forward: prepares every registered weight image in one launch."""
         global ACTIVE
         ACTIVE = self
+        FORKED_STREAMS.clear()
         if not self.entries:
             return
         if self._dirty:
@@ -171,6 +190,7 @@ class WeightBank:
     def _finish(self):
         """Runs once at the end of the backward pass: all weight gradients in one launch."""
         self._cb_queued = False
+        join_forked_streams()
         call("hdmoe_wbank_bwd", self._descs, self._rows, self._nrows)
 
 

@@ -36,6 +36,11 @@ class GradBuckets:
         self._works = [None] * len(self.buckets)
         self._next = 0                                             # collectives are issued strictly in bucket order
         self.enabled = True                                        # False: hooks only count (e.g. while capturing a hipGraph)
+        # Hooks fire on whatever stream the gradient was produced on.  With the ViT experts forked onto side streams a bucket can
+        # be completed on one stream while another still writes a neighbouring slice, so eager launches are only safe when the
+        # whole step runs on one stream; otherwise every bucket goes out in finish(), after autograd has joined the streams.
+        from . import ops as _ops
+        self.eager = not _ops.SIDE_STREAMS
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         for bi, members in enumerate(self._members):
             for p in members:
@@ -56,6 +61,8 @@ class GradBuckets:
             if not self.enabled:
                 return
             self._pending[bi] += 1
+            if not self.eager:
+                return
             # every rank must issue the same collectives in the same order, but which hooks fire (and when) depends on
             # the local routing: launch only the contiguous prefix of complete buckets, the rest waits for finish()
             while self._next < len(self.buckets) and self._pending[self._next] == len(self._members[self._next]):

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import bank, ops
 
 
 class GraphedStep:
@@ -28,6 +28,7 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             ops.advance_seed(self.device)
             self.out = step_fn()
+            bank.join_forked_streams()                  # every forked side stream is back on the capture stream
 
     def __call__(self):
         self.graph.replay()

@@ -50,6 +50,20 @@ def _next_seed() -> int:
 
 _step_counters = {}
 
+# Independent, launch-latency-bound branches of the model (the ViT experts) run on side streams beside the main stream's
+# large launches; HDMOE_SIDE_STREAMS=0 serialises everything on the caller's stream.
+import os as _os
+SIDE_STREAMS = _os.environ.get("HDMOE_SIDE_STREAMS", "1") != "0"
+_side_pool = {}
+
+
+def side_streams(device, n: int):
+    key = torch.device(device)
+    pool = _side_pool.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=key))
+    return pool[:n]
+
 
 def step_counter(device) -> Tensor:
     """Device-resident step counter mixed into every dropout / noise Philox key (see csrc/elementwise.hip: mix_seed)."""
@@ -96,7 +110,15 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
     lds = 80 * ((th + max(khs) - 1) * (tw + max(kws) - 1) + max(kws) * 32 * nt)
     halo = (th + max(khs) - 1) * (tw + max(kws) - 1)
     if Ho * Wo >= 64 and vec and halo * 4 <= 7 * 256 and max(kws) * 32 * nt <= 576:
-        fwd_name = f"conv_fwd3_kernel<{tname}, {nt}>"
+        tg = min(576 // (max(kws) * 32 * nt), max(khs))
+        while tg > 1 and 80 * (halo + tg * max(kws) * 32 * nt) > 64 * 1024:
+            tg -= 1
+        lds3 = 80 * (halo + tg * max(kws) * 32 * nt)
+        if I == cphys and Cstore % 4 == 0 and lds3 <= 64 * 1024:
+            lepi = Cstore % (16 // esz) == 0 and 4 * 64 * (32 * nt + 16 // esz) * esz <= lds3
+            fwd_name = f"conv_fwd5_kernel<{tname}, {nt}, {'true' if lepi else 'false'}>"
+        else:
+            fwd_name = f"conv_fwd3_kernel<{tname}, {nt}>"
     elif Ho * Wo >= 64 and lds <= 64 * 1024:
         fwd_name = f"conv_fwd2_kernel<{tname}, {nt}, {'true' if vec else 'false'}>"
     else:

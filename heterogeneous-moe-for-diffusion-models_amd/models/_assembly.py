@@ -34,15 +34,40 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
         ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg)
         return ops.combine_rows(ys, out_router, plan)
-    # ViT experts have per-expert token counts (heterogeneous patch sizes) and are FLOP-trivial (<1 % of a step):
-    # evaluate each on the whole batch and keep only the routed samples (weight 0 elsewhere) -- still sync-free.
-    out = None
-    for i, expert in enumerate(mods):
-        w = ops.take_col_pos(out_router, i)                       # (B,): weight where routed, exact 0 elsewhere
+    return _combine_weighted(_run_experts(x, mods, time_emb, text2d), out_router)
+
+
+def _run_experts(x: Tensor, mods: List[nn.Module], time_emb: Tensor, text2d: Optional[Tensor]):
+    """ViT experts have per-expert token counts (heterogeneous patch sizes) and are FLOP-trivial (<1 % of a step) but
+    launch-latency-bound (hundreds of few-microsecond kernels): each is evaluated on the whole batch -- still sync-free --
+    on its own side stream, so the experts overlap each other and whatever the caller's stream does until the outputs are
+    combined.  Returns (outputs, streams to join)."""
+    def one(expert):
         if isinstance(expert, m.Vit_expert):
-            y = expert._fwd(x, time_emb, text2d)
-        else:
-            y = ops.to_nhwc(expert(x=ops.from_nhwc(x), time_emb=time_emb, text_emb=text2d))
+            return expert._fwd(x, time_emb, text2d)
+        return ops.to_nhwc(expert(x=ops.from_nhwc(x), time_emb=time_emb, text_emb=text2d))
+    if not (ops.SIDE_STREAMS and x.is_cuda and len(mods) > 1):
+        return [one(e) for e in mods], None
+    main = torch.cuda.current_stream()
+    streams = ops.side_streams(x.device, len(mods))
+    ys = []
+    for s, expert in zip(streams, mods):
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            ys.append(one(expert))
+    wbank.note_forked_streams(streams)
+    return ys, streams
+
+
+def _combine_weighted(job, out_router: Tensor) -> Tensor:
+    ys, streams = job
+    if streams is not None:
+        main = torch.cuda.current_stream()
+        for s in streams:
+            main.wait_stream(s)
+    out = None
+    for i, y in enumerate(ys):
+        w = ops.take_col_pos(out_router, i)                       # (B,): weight where routed, exact 0 elsewhere
         y = ops.scale_rows(y, w)
         out = y if out is None else ops.axpby(out, y, 1.0, 1.0)
     return out
@@ -126,16 +151,24 @@ class _HDMOEMBase(nn.Module):
         s_vit, s_unet, scaling = self._scaling(time_vec, te, zeta, **kw)
         in_unet = ops.scale_rows(feats, s_unet)
         in_vit = ops.scale_rows(feats, s_vit)
-        w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
-        w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
         text2d = None
         text_c = None
         if text_emb is not None:
             text32 = ops.cast(text_emb, torch.float32)
             text2d = ops.seq_mean(text32) if text32.ndim == 3 else text32
             text_c = ops.cast(text32, cdt)
+        # the ViT experts need only the stem features: fork them now, they run beside the routers and the U-Net bank
+        vit_mods = list(self.VIT_experts)
+        vit_job = None
+        if not (all(isinstance(e, m.Unet_expert) for e in vit_mods) and len(vit_mods) <= 8):
+            vit_job = _run_experts(ops.cast(in_vit, cdt), vit_mods, te, text2d)
+        w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
+        w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
         out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
-        out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
+        if vit_job is not None:
+            out_v = _combine_weighted(vit_job, w_vit)
+        else:
+            out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
         C = self.internal_channels
         fu = out_u.reshape(B, H * W, C)                                     # channel-last image == (B, S, C) tokens
         fv = out_v.reshape(B, H * W, C)

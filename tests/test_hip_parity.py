@@ -767,3 +767,57 @@ def test_trainer_iteration_and_checkpoint_roundtrip(tmp_path):
     opt2.step()
     assert int(next(iter(opt2.state.values()))["step"]) == 4
     hdmoe_hip.set_compute_dtype(torch.float32)
+
+
+def test_graph_replay_with_side_streams_matches_single_stream_eager():
+    """The benchmarked configuration -- whole step replayed as one hipGraph, ViT experts forked onto side streams -- must
+    produce the gradients of the plain single-stream eager step (same inputs, eval mode so no dropout / logit noise)."""
+    import hdmoe_hip
+    from hdmoe_hip import ops
+    from hdmoe_hip.graph import GraphedStep
+    from hdmoe_hip.dp import GradBuckets
+    from Utils import configs
+    from Utils.utils import EDM_LOSS
+    from models import model_config1
+    from oracle.recipe import fill_state, make_inputs
+    hdmoe_hip.set_compute_dtype(torch.float32)
+    kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
+    model = model_config1.preconditioned_HDMOEM(**kw)
+    model.load_state_dict(fill_state(model.state_dict(), 5))
+    model = model.to(DEV).eval()
+    inp = {k: v.to(DEV) for k, v in make_inputs(6, 4, 32, 4, 77, 768, 5).items()}
+    crit = EDM_LOSS(num_experts=4, sigma_data=0.5, Unet_bal=0.05, vit_bal=0.1, z_bal=0.005, prior_bal=0.0)
+    buckets = GradBuckets(model)
+
+    def fwd_bwd():
+        buckets.zero_grad()
+        out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["unet_mask"],
+                    Vit_router_mask=inp["vit_mask"], zeta=0.0, return_log_var=True)
+        loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+        loss["loss"].backward()
+        return loss["loss"].detach()
+
+    saved = ops.SIDE_STREAMS
+    try:
+        ops.SIDE_STREAMS = False
+        for _ in range(2):                               # second pass runs through the weight bank
+            l_ref = fwd_bwd()
+        torch.cuda.synchronize()
+        ref = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        ops.SIDE_STREAMS = True
+        graphed = GraphedStep(fwd_bwd, DEV)
+        for _ in range(3):
+            l_g = graphed()
+        torch.cuda.synchronize()
+    finally:
+        ops.SIDE_STREAMS = saved
+    close(l_g, l_ref, rtol=1e-5, atol=1e-6, msg="loss")
+    bad = []
+    for n, p in model.named_parameters():
+        if n in ref:
+            scale = float(ref[n].abs().max())
+            err = float((p.grad - ref[n]).abs().max())
+            if err > 2e-4 * scale + 1e-7:
+                bad.append((n, err, scale))
+    assert not bad, bad[:5]
+    assert len(ref) > 400
