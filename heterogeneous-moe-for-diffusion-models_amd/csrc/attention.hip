@@ -5,6 +5,7 @@
 // Head dim is tiny here (D = E/H = 4): QK^T has K = 4, so this is exp/VALU work, not MFMA work.  One thread owns
 // one query row (fwd, dq) or one key row (dk/dv); the other side streams through LDS in fp32 tiles and is
 // read by every lane at the same address (LDS broadcast, conflict-free).
+#include <stdlib.h>
 #include "common.h"
 #include "hdmoe.h"
 
@@ -201,9 +202,308 @@ __global__ void attn_dbias_kernel(float* dbias, const T* dout, const T* q, const
   dbias[((long)h * Sb + i) * Sb + j] = acc;
 }
 
+// =====================================================================================================================
+// MFMA path: bf16, D = 4, no positional bias (the fusion cross-attention S = 1024 and the text cross-attention S_kv = 77).
+// The one-row-per-thread kernels above spend ~15 VALU instructions per (q, k) pair (4 cycles each on a wave64); here the
+// three contractions of a 32 x 32 tile run on the matrix pipe with the head dim zero-padded 4 -> 16 (75 % of each MFMA is
+// padding, still ~8x cheaper than the VALU form) and only the softmax arithmetic stays on the vector pipe.
+//   S^T[k][q]  = K[k][:] . Q[q][:]            A = K rows (LDS),        B = Q (registers, fixed per wave)
+//   O^T[d][q] += V^T[d][k] * P^T[k][q]        A = V^T (LDS, permuted), B = P straight from the S^T accumulator registers
+// An accumulator lane (c, hh) holds column q = c and rows k = (reg&3) + 8(reg>>2) + 4hh, i.e. for the 16-deep slice s of the
+// second product its registers 8s..8s+7 ARE a B-operand fragment if K-slot (hh, j) is defined as k = 16s + (j&3) + 8(j>>2) + 4hh;
+// the A operand (V^T, or K^T / Q^T / dO^T in the backward kernels) is staged in LDS in exactly that slot order (kslot()), so
+// no cross-lane movement is needed.  Row 4 of the padded V^T tile is all ones: O^T row 4 accumulates the softmax denominator
+// on the matrix pipe for free.  One workgroup = one 32-row block x all heads (wave w = head w), so K/V rows are loaded whole.
+constexpr int MK = 128;                                      // rows staged per barrier
+DEVI f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVI bf16x8 pack8(const f32x16& v, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
+  return o;
+}
+// fragment [x0 x1 x2 x3 0 0 0 0] on lanes hh == 0, zeros on hh == 1 (head dim 4 padded to the 16-deep K of the MFMA)
+DEVI bf16x8 head_frag(const bf16* row, bool valid) {
+  bf16x8 f = (bf16x8)(0);
+  if (valid) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(row);
+    f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
+  }
+  return f;
+}
+// LDS image of a staged [rows][E] bf16 tensor: per head MK + 1 rows of 16 bytes, [x0 x1 x2 x3 e4 0 0 0] (e4 = 1 for V in the
+// forward kernel, else 0); row MK is all zeros.  Consecutive threads take consecutive heads of one row: whole global rows,
+// and the 16-byte LDS writes of the 8 heads land 2064 B apart = on disjoint bank quads (conflict-free).
+struct StageRegs { uint2 v[2]; };
+DEVI void stage_load(StageRegs& rg, const bf16* src, long row0, int nrows_valid, int H, int tid, int nthr) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * nthr;
+    const int rr = idx / H, hd = idx - rr * H;
+    uint2 t = make_uint2(0, 0);
+    if (rr < nrows_valid) t = *reinterpret_cast<const uint2*>(src + (row0 + rr) * (long)(H * 4) + hd * 4);
+    rg.v[i] = t;
+  }
+}
+DEVI void stage_write(const StageRegs& rg, bf16* rowL, unsigned e4, int H, int tid, int nthr) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * nthr;
+    const int rr = idx / H, hd = idx - rr * H;
+    *reinterpret_cast<uint4*>(rowL + ((long)hd * (MK + 1) + rr) * 8) = make_uint4(rg.v[i].x, rg.v[i].y, e4, 0);
+  }
+}
+// A-operand fragment of X^T (rows = head-dim index, 8 K-slots of slice s) straight from the row image X[k][8] with the
+// hardware transposing read (cdna_hip_programming.md T10): within a 16-lane group lane 4q+p addresses row q, columns 4p..4p+3
+// and lane i receives column i of the four rows.  Lane (r, hh) so gets X[16s + j' + 8*(second read) + 4hh][r] -- the K-slot
+// order of the accumulator registers.  Columns 8..15 of a "row" are the next row's bytes: they only feed MFMA output rows
+// 8..31, which nobody reads.  The per-lane address is tr_base(); +64 elements = 8 rows for the second read.
+DEVI int tr_base(int lane) { return ((((lane & 15) >> 2) + 4 * (lane >> 5)) * 8) + 4 * (lane & 3); }
+DEVI bf16x8 tr_frag(const bf16* p) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 64));
+  return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+DEVI void zero_row(bf16* rowL, int H, int tid, int nthr) {
+  for (int e = tid; e < H * 8; e += nthr) rowL[((long)(e >> 3) * (MK + 1) + MK) * 8 + (e & 7)] = (bf16)0.f;
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(bf16* out, float* lse, const bf16* q, const bf16* k, const bf16* v, int Sq,
+                                                           int Skv, int H, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  bf16* rowK = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
+  bf16* rowV = rowK + (long)H * (MK + 1) * 8;                 // [H][MK+1][8], element 4 of every row = 1
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, q0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
+  zero_row(rowK, H, tid, nthr);
+  zero_row(rowV, H, tid, nthr);
+  const bool qok = q0 + r < Sq;
+  const bf16x8 fq = head_frag(q + ((long)b * Sq + q0 + (qok ? r : 0)) * E + h * 4, hh == 0 && qok);
+  const bf16* aK = rowK + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
+  const int aKstep = hh == 0 ? 32 * 8 : 0;
+  const bf16* aV = rowV + (long)h * (MK + 1) * 8 + tr_base(lane);
+  f32x16 o = (f32x16)(0.f);
+  float m = -INFINITY;
+  StageRegs rk, rv;
+  stage_load(rk, k, (long)b * Skv, min(MK, Skv), H, tid, nthr);
+  stage_load(rv, v, (long)b * Skv, min(MK, Skv), H, tid, nthr);
+  for (int j0 = 0; j0 < Skv; j0 += MK) {
+    __syncthreads();                                         // readers of the previous stage are done
+    stage_write(rk, rowK, 0u, H, tid, nthr);
+    stage_write(rv, rowV, 0x3F80u, H, tid, nthr);            // bf16 1.0 in column 4: O^T row 4 = sum_k P = softmax denominator
+    __syncthreads();
+    if (j0 + MK < Skv) {
+      stage_load(rk, k, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
+      stage_load(rv, v, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
+    }
+    const int nt = min(MK / 32, (Skv - j0 + 31) >> 5);
+    for (int t = 0; t < nt; ++t) {
+      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(aK + t * aKstep);
+      const bf16x8 fv0 = tr_frag(aV + t * 256);
+      const bf16x8 fv1 = tr_frag(aV + t * 256 + 128);
+      f32x16 s = mfma_bf16(fk, fq, (f32x16)(0.f));           // rows = keys, columns = queries
+      const int kb = j0 + t * 32;
+      if (kb + 32 > Skv) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (kb + acc_row(reg, lane) >= Skv) s[reg] = -INFINITY;
+      }
+      float tm = s[0];
+#pragma unroll
+      for (int reg = 1; reg < 16; ++reg) tm = fmaxf(tm, s[reg]);
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                // the other half-wave holds the other 16 keys of these queries
+      const float mn = fmaxf(m, tm);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      m = mn;
+      const float nm = -mn * c;
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;     // rows 0-3 (hh = 0) and the denominator row 4 (hh = 1)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(fmaf(s[reg], c, nm));
+      o = mfma_bf16(fv0, pack8(s, 0), o);
+      o = mfma_bf16(fv1, pack8(s, 1), o);
+    }
+  }
+  const float l = __shfl_xor(o[0], 32, 64);                  // row 4 of O^T (lane + 32, register 0) = sum of the probabilities
+  if (hh == 0 && qok) {
+    const float il = 1.f / l;
+    bf16x4 ov;
+    ov[0] = (bf16)(o[0] * il); ov[1] = (bf16)(o[1] * il); ov[2] = (bf16)(o[2] * il); ov[3] = (bf16)(o[3] * il);
+    *reinterpret_cast<bf16x4*>(out + ((long)b * Sq + q0 + r) * E + h * 4) = ov;
+    lse[((long)b * H + h) * Sq + q0 + r] = (m * c + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  }
+}
+
+// dq (+ delta): wave = (head, 32 queries); keys stream through LDS.
+__global__ __launch_bounds__(512) void attn_bwd_dq_mfma_kernel(bf16* dq, float* delta, const bf16* dout, const bf16* out, const bf16* q,
+                                                              const bf16* k, const bf16* v, const float* lse, int Sq, int Skv, int H,
+                                                              float scale, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  bf16* rowK = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
+  bf16* rowV = rowK + (long)H * (MK + 1) * 8;                 // [H][MK+1][8]
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, q0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
+  zero_row(rowK, H, tid, nthr);
+  zero_row(rowV, H, tid, nthr);
+  const bool qok = q0 + r < Sq;
+  const long qoff = ((long)b * Sq + q0 + (qok ? r : 0)) * E + h * 4;
+  const bf16x8 fq = head_frag(q + qoff, hh == 0 && qok);
+  const bf16x8 fdo = head_frag(dout + qoff, hh == 0 && qok);
+  float dl = 0.f, ls = 0.f;
+  if (qok) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(dout + qoff), o4 = *reinterpret_cast<const bf16x4*>(out + qoff);
+    dl = (float)a[0] * (float)o4[0] + (float)a[1] * (float)o4[1] + (float)a[2] * (float)o4[2] + (float)a[3] * (float)o4[3];
+    ls = lse[((long)b * H + h) * Sq + q0 + r] * 1.4426950408889634f;
+    if (hh == 0) delta[((long)b * H + h) * Sq + q0 + r] = dl;
+  }
+  const long lstep = hh == 0 ? 32 * 8 : 0;
+  const bf16* aK = rowK + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
+  const bf16* aVr = rowV + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
+  const bf16* aKt = rowK + (long)h * (MK + 1) * 8 + tr_base(lane);
+  f32x16 acc = (f32x16)(0.f);
+  StageRegs rk, rv;
+  stage_load(rk, k, (long)b * Skv, min(MK, Skv), H, tid, nthr);
+  stage_load(rv, v, (long)b * Skv, min(MK, Skv), H, tid, nthr);
+  for (int j0 = 0; j0 < Skv; j0 += MK) {
+    __syncthreads();
+    stage_write(rk, rowK, 0u, H, tid, nthr);
+    stage_write(rv, rowV, 0u, H, tid, nthr);
+    __syncthreads();
+    if (j0 + MK < Skv) {
+      stage_load(rk, k, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
+      stage_load(rv, v, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
+    }
+    const int nt = min(MK / 32, (Skv - j0 + 31) >> 5);
+    for (int t = 0; t < nt; ++t) {
+      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(aK + t * lstep);
+      const bf16x8 fv = *reinterpret_cast<const bf16x8*>(aVr + t * lstep);
+      const bf16x8 fk0 = tr_frag(aKt + t * 256);
+      const bf16x8 fk1 = tr_frag(aKt + t * 256 + 128);
+      f32x16 s = mfma_bf16(fk, fq, (f32x16)(0.f));           // S^T[k][q]
+      const f32x16 dp = mfma_bf16(fv, fdo, (f32x16)(0.f));   // dP^T[k][q] = V[k] . dO[q]
+      // keys past Skv are zero rows: their ds is finite and meets a zero K^T column, so no masking is needed
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(fmaf(s[reg], c, -ls)) * (dp[reg] - dl);
+      acc = mfma_bf16(fk0, pack8(s, 0), acc);                // dQ^T[d][q] += K^T[d][k] dS^T[k][q]
+      acc = mfma_bf16(fk1, pack8(s, 1), acc);
+    }
+  }
+  if (hh == 0 && qok) {
+    bf16x4 ov;
+    ov[0] = (bf16)(acc[0] * scale); ov[1] = (bf16)(acc[1] * scale); ov[2] = (bf16)(acc[2] * scale); ov[3] = (bf16)(acc[3] * scale);
+    *reinterpret_cast<bf16x4*>(dq + qoff) = ov;
+  }
+}
+
+// dk, dv: wave = (head, 32 keys); queries (+ dO, lse, delta) stream through LDS.
+__global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(bf16* dk, bf16* dv, const bf16* dout, const bf16* q, const bf16* k,
+                                                               const bf16* v, const float* lse, const float* delta, int Sq, int Skv,
+                                                               int H, float scale, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  bf16* rowQ = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
+  bf16* rowD = rowQ + (long)H * (MK + 1) * 8;                 // [H][MK+1][8]
+  float* sl = reinterpret_cast<float*>(rowD + (long)H * (MK + 1) * 8);   // [H][MK] lse * log2(e)  (+inf past Sq)
+  float* sd = sl + (long)H * MK;                              // [H][MK] delta
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, k0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
+  zero_row(rowQ, H, tid, nthr);
+  zero_row(rowD, H, tid, nthr);
+  const bool kok = k0 + r < Skv;
+  const long koff = ((long)b * Skv + k0 + (kok ? r : 0)) * E + h * 4;
+  const bf16x8 fkB = head_frag(k + koff, hh == 0 && kok);
+  const bf16x8 fvB = head_frag(v + koff, hh == 0 && kok);
+  const long lstep = hh == 0 ? 32 * 8 : 0;
+  const bf16* aQ = rowQ + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
+  const bf16* aD = rowD + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
+  const bf16* aQt = rowQ + (long)h * (MK + 1) * 8 + tr_base(lane);
+  const bf16* aDt = rowD + (long)h * (MK + 1) * 8 + tr_base(lane);
+  const float* pl = sl + (long)h * MK + 4 * hh;
+  const float* pd = sd + (long)h * MK + 4 * hh;
+  f32x16 ak = (f32x16)(0.f), av = (f32x16)(0.f);
+  StageRegs rq, rd;
+  float rl[2], rdl[2];
+  auto load_ld = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * nthr;
+      const int rr = idx / H, hd = idx - rr * H;
+      const bool ok = i0 + rr < Sq;
+      rl[i] = ok ? lse[((long)b * H + hd) * Sq + i0 + rr] * 1.4426950408889634f : INFINITY;
+      rdl[i] = ok ? delta[((long)b * H + hd) * Sq + i0 + rr] : 0.f;
+    }
+  };
+  stage_load(rq, q, (long)b * Sq, min(MK, Sq), H, tid, nthr);
+  stage_load(rd, dout, (long)b * Sq, min(MK, Sq), H, tid, nthr);
+  load_ld(0);
+  for (int i0 = 0; i0 < Sq; i0 += MK) {
+    __syncthreads();
+    stage_write(rq, rowQ, 0u, H, tid, nthr);
+    stage_write(rd, rowD, 0u, H, tid, nthr);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * nthr;
+      const int rr = idx / H, hd = idx - rr * H;
+      sl[(long)hd * MK + rr] = rl[i];
+      sd[(long)hd * MK + rr] = rdl[i];
+    }
+    __syncthreads();
+    if (i0 + MK < Sq) {
+      stage_load(rq, q, (long)b * Sq + i0 + MK, min(MK, Sq - i0 - MK), H, tid, nthr);
+      stage_load(rd, dout, (long)b * Sq + i0 + MK, min(MK, Sq - i0 - MK), H, tid, nthr);
+      load_ld(i0 + MK);
+    }
+    const int nt = min(MK / 32, (Sq - i0 + 31) >> 5);
+    for (int t = 0; t < nt; ++t) {
+      const bf16x8 fqr = *reinterpret_cast<const bf16x8*>(aQ + t * lstep);
+      const bf16x8 fdr = *reinterpret_cast<const bf16x8*>(aD + t * lstep);
+      const bf16x8 fd0 = tr_frag(aDt + t * 256), fd1 = tr_frag(aDt + t * 256 + 128);
+      const bf16x8 fq0 = tr_frag(aQt + t * 256), fq1 = tr_frag(aQt + t * 256 + 128);
+      f32x16 s = mfma_bf16(fqr, fkB, (f32x16)(0.f));          // S[q][k]: rows = queries, columns = keys
+      f32x16 dp = mfma_bf16(fdr, fvB, (f32x16)(0.f));         // dP[q][k] = dO[q] . V[k]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                           // register quad i = queries 8i + 4hh .. +3 of the tile
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(pl + t * 32 + 8 * i);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(pd + t * 32 + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * i + j], c, -l4[j]));    // 0 for queries past Sq (lse = +inf)
+          s[4 * i + j] = p;
+          dp[4 * i + j] = p * (dp[4 * i + j] - d4[j]);
+        }
+      }
+      av = mfma_bf16(fd0, pack8(s, 0), av);                   // dV^T[d][k] += dO^T[d][q] P[q][k]
+      av = mfma_bf16(fd1, pack8(s, 1), av);
+      ak = mfma_bf16(fq0, pack8(dp, 0), ak);                  // dK^T[d][k] += Q^T[d][q] dS[q][k]
+      ak = mfma_bf16(fq1, pack8(dp, 1), ak);
+    }
+  }
+  if (hh == 0 && kok) {
+    bf16x4 ok4, ov4;
+    ok4[0] = (bf16)(ak[0] * scale); ok4[1] = (bf16)(ak[1] * scale); ok4[2] = (bf16)(ak[2] * scale); ok4[3] = (bf16)(ak[3] * scale);
+    ov4[0] = (bf16)av[0]; ov4[1] = (bf16)av[1]; ov4[2] = (bf16)av[2]; ov4[3] = (bf16)av[3];
+    *reinterpret_cast<bf16x4*>(dk + koff) = ok4;
+    *reinterpret_cast<bf16x4*>(dv + koff) = ov4;
+  }
+}
+
+static inline bool attn_mfma_ok(int H, const void* a, const void* b2, const void* c2, const void* d2) {
+  static const bool off = getenv("HDMOE_ATTN_VALU") != nullptr;
+  return !off && H >= 1 && H <= 8 && (((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 7) == 0;
+}
+
 template <typename T, int D>
 int attn_fwd_launch(void* out, float* lse, const void* q, const void* k, const void* v, const float* bias, int B, int Sq, int Skv,
                     int H, int Sb, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && D == 4) {
+    if (!bias && attn_mfma_ok(H, out, q, k, v)) {
+      const size_t lds = (size_t)H * 2 * (MK + 1) * 16;
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds, st, (bf16*)out, lse, (const bf16*)q, (const bf16*)k,
+                         (const bf16*)v, Sq, Skv, H, 1.4426950408889634f / sqrtf((float)D));
+      return hdmoe_launch_status();
+    }
+  }
   dim3 grid(cdiv(Sq, TQ), H, B);
   if (bias) hipLaunchKernelGGL((attn_fwd_kernel<T, D, true>), grid, dim3(TQ), 0, st, (T*)out, lse, (const T*)q, (const T*)k, (const T*)v, bias, Sq,
                      Skv, H, Sb, 1.f / sqrtf((float)D));
@@ -216,6 +516,18 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
                     const void* k, const void* v, const float* lse, const float* bias, int B, int Sq, int Skv, int H, int Sb,
                     hipStream_t st) {
   const float scale = 1.f / sqrtf((float)D);
+  if constexpr (sizeof(T) == 2 && D == 4) {
+    if (!bias && attn_mfma_ok(H, dq, dk, dv, dout) && attn_mfma_ok(H, out, q, k, v)) {
+      const float c = scale * 1.4426950408889634f;
+      const size_t lds_q = (size_t)H * 2 * (MK + 1) * 16;
+      const size_t lds_kv = (size_t)H * (2 * (MK + 1) * 16 + 2 * MK * 4);
+      hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds_q, st, (bf16*)dq, delta, (const bf16*)dout,
+                         (const bf16*)out, (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, Sq, Skv, H, scale, c);
+      hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(Skv, 32), B), dim3(64 * H), lds_kv, st, (bf16*)dk, (bf16*)dv, (const bf16*)dout,
+                         (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, Sq, Skv, H, scale, c);
+      return hdmoe_launch_status();
+    }
+  }
 #define ATTN_BWD(BB)                                                                                                                  \
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, BB>), dim3(cdiv(Sq, TQ), H, B), dim3(TQ), 0, st, (T*)dq, delta, dbias, (const T*)dout,  \
                      (const T*)out, (const T*)q, (const T*)k, (const T*)v, lse, bias, Sq, Skv, H, Sb, scale);                          \
