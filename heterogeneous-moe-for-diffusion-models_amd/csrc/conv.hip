@@ -952,53 +952,64 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   constexpr int NX = sizeof(T) == 2 ? 6 : 8;                  // halo chunks per thread held in registers (host checks the cap)
   uint4 rdy[VEC ? NDY : 1], rx[VEC ? NX : 1];
   // unit -> (sample, tile origin); large unit indices (flattened linear layers) take the exact division
+  // (q * magic) >> 20 with magic = 2^20/d + 1 overshoots floor(q/d) by at most one for q < 2^20 and is exact only while
+  // q * d < 2^20 -- not guaranteed here (a flattened 262144-pixel row has d = tpn = 2048 tiles): fix the quotient up.
   auto unit_origin = [&](int u, int& n, int& ty0, int& tx0) {
-    n = u < (1 << 12) ? fast_div(u, magic_tpn) : u / tpn;
+    if (u < (1 << 12)) { n = fast_div(u, magic_tpn); if (n * tpn > u) --n; } else n = u / tpn;
     const int tyx = u - n * tpn;
-    const int tyi = tyx < (1 << 12) ? fast_div(tyx, magic_tx) : tyx / gm.tiles_x;
+    int tyi;
+    if (tyx < (1 << 12)) { tyi = fast_div(tyx, magic_tx); if (tyi * gm.tiles_x > tyx) --tyi; } else tyi = tyx / gm.tiles_x;
     ty0 = tyi * TH; tx0 = (tyx - tyi * gm.tiles_x) * TW;
   };
+  // Branch-free staging (VEC path: Cphys and Cout are multiples of the 16-byte vector): every piece is loaded from a CLAMPED,
+  // always-valid address and per-thread bit masks remember which pieces are real; the masks are applied when the registers
+  // are published to LDS.  (Predicated loads cost ~100 spilled SGPRs of saved exec masks here, and spill reloads -- vector
+  // memory operations themselves -- put an s_waitcnt vmcnt(0) in front of the loads that follow them.)
+  unsigned dymask = 0, xmask = 0, xinb = 0;
   auto prefetch = [&](int u) {                                 // global -> registers (VEC path)
     int n, ty0, tx0;
     unit_origin(u, n, ty0, tx0);
     const int rows_valid = min(TH, a.Ho - ty0);
+    const int cols_valid = min(TW, a.Wo - tx0);
     const T* dyn = DY + (((long)n * a.Ho + ty0) * a.Wo + tx0) * a.Cout + o0;
+    const int cmax = a.Cout - o0 - VW;                         // last whole vector of this o-block that exists
+    dymask = 0;
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
       const int idx = tid + k * 256;
       const int pq = idx / CPP, c = (idx - pq * CPP) * VW;
       const int ty = div_tw(pq), tx = pq - ty * TW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pq < TH * TW && ty < rows_valid && tx0 + tx < a.Wo && o0 + c < a.Cout)
-        v = *reinterpret_cast<const uint4*>(dyn + ((long)ty * a.Wo + tx) * a.Cout + c);
-      rdy[k] = v;
+      const bool ok = pq < TH * TW && ty < rows_valid && tx < cols_valid && c <= cmax;
+      const int tyc = min(ty, rows_valid - 1), txc = min(tx, cols_valid - 1), cc = max(min(c, cmax), -o0);
+      rdy[k] = *reinterpret_cast<const uint4*>(dyn + ((long)tyc * a.Wo + txc) * a.Cout + cc);
+      dymask |= (ok ? 1u : 0u) << k;
     }
     const T* xn = X + (long)n * a.H * a.W * a.Cphys;
+    xmask = 0; xinb = 0;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int idx = tid + k * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < nh) {
-        const int px = idx / XPP, c = (idx - px * XPP) * VW;
-        const int hy = fast_div(px, magic_hw), hx = px - hy * HWp;
-        const int iy = ty0 + hy - pt, ix = tx0 + hx - pl, ci = i0 + c;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-          if (ci + VW <= a.Cphys) v = *reinterpret_cast<const uint4*>(xn + ((long)iy * a.W + ix) * a.Cphys + ci);
-          else {
-            T tmp[VW];
-#pragma unroll
-            for (int j = 0; j < VW; ++j) {
-              T e = zero;
-              if (ci + j < a.Cphys) e = xn[((long)iy * a.W + ix) * a.Cphys + ci + j];
-              else if (a.ones && ci + j == a.Cphys) e = from_f<T>(1.f);
-              tmp[j] = e;
-            }
-            v = *reinterpret_cast<const uint4*>(tmp);
-          }
-        }
-      }
-      rx[k] = v;
+      const int idx = min(tid + k * 256, nh - 1);
+      const int px = idx / XPP, c = (idx - px * XPP) * VW;
+      const int hy = fast_div(px, magic_hw), hx = px - hy * HWp;
+      const int iy = ty0 + hy - pt, ix = tx0 + hx - pl, ci = i0 + c;
+      const bool inb = tid + k * 256 < nh && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const bool ok = inb && ci < a.Cphys;
+      const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1), cic = min(ci, a.Cphys - VW);
+      rx[k] = *reinterpret_cast<const uint4*>(xn + ((long)iyc * a.W + ixc) * a.Cphys + cic);
+      xmask |= (ok ? 1u : 0u) << k;
+      xinb |= (inb ? 1u : 0u) << k;
     }
+  };
+  // value of an x piece that was not loaded: zero (padding pixels, channels past Cin), or the implicit ones channel
+  // (channel Cphys of an in-bounds pixel) in its first element
+  auto const_piece = [&](int ci, bool inb) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (a.ones && inb && ci == a.Cphys) {
+      const T one = from_f<T>(1.f);
+      if constexpr (sizeof(T) == 2) v.x = (unsigned)__builtin_bit_cast(unsigned short, one);
+      else v.x = __builtin_bit_cast(unsigned, one);
+    }
+    return v;
   };
 
   if (VEC) prefetch(u0);
@@ -1012,12 +1023,17 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
       for (int k = 0; k < NDY; ++k) {
         const int idx = tid + k * 256;
         const int pq = idx / CPP, c = (idx - pq * CPP) * VW;
-        if (pq < TH * TW) *reinterpret_cast<uint4*>(sdy + pq * OBP + c) = rdy[k];
+        const uint4 v = (dymask >> k) & 1u ? rdy[k] : make_uint4(0, 0, 0, 0);
+        if (pq < TH * TW) *reinterpret_cast<uint4*>(sdy + pq * OBP + c) = v;
       }
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
         const int idx = tid + k * 256;
-        if (idx < nh) *reinterpret_cast<uint4*>(sx + (idx / XPP) * WG2_IB + (idx % XPP) * VW) = rx[k];
+        if (idx < nh) {
+          const int c = (idx % XPP) * VW;
+          const uint4 v = (xmask >> k) & 1u ? rx[k] : const_piece(i0 + c, (xinb >> k) & 1u);
+          *reinterpret_cast<uint4*>(sx + (idx / XPP) * WG2_IB + c) = v;
+        }
       }
     } else {
       const int rows_valid = min(TH, a.Ho - ty0);

@@ -456,6 +456,22 @@ def test_mp_conv_vs_oracle(dtype, rel, cin, cout, k, hw):
     close_scaled(wd.grad, wr.grad, rel, msg="dw")
 
 
+@pytest.mark.parametrize("rows", [2045 * 128, 262144, 3000 * 128 + 64])
+def test_pointwise_wgrad_on_a_long_flattened_row(rows):
+    """BASELINE-size token counts: an ungrouped 1x1 layer runs as ONE flattened row of B*S pixels (262144 at B = 256, S = 1024,
+    i.e. 2048 pixel tiles).  The unit -> (sample, tile) decode used a 20-bit reciprocal that is off by one from tile 2045 on;
+    the weight gradient must match a plain fp32 matmul for tile counts on both sides of that edge."""
+    from hdmoe_hip import ops
+    torch.manual_seed(rows % 1000)
+    x = torch.randn(1, rows, 64, device=DEV).to(torch.bfloat16)
+    w = torch.randn(32, 64, 1, 1, device=DEV, requires_grad=True)
+    gy = torch.randn(1, rows, 32, device=DEV).to(torch.bfloat16)
+    out = ops.mp_conv(x.view(1, 1, rows, 64).requires_grad_(True), w, 1.0, normalize=False)
+    out.backward(gy.view(1, 1, rows, 32))
+    ref = gy.view(rows, 32).float().t() @ x.view(rows, 64).float()            # dW[o][i] = sum_px dy[px][o] x[px][i]
+    close_scaled(w.grad.view(32, 64), ref, 2e-3, msg="dw")                     # bf16 inputs, fp32 accumulation on both sides
+
+
 @pytest.mark.parametrize("dtype,rel", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
 def test_grouped_conv_heterogeneous_kernels(dtype, rel):
     """One launch, three experts with 3x3 / 5x5 / 7x7 kernels over expert-contiguous rows (incl. an empty expert)."""
