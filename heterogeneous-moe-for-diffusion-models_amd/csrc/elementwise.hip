@@ -279,6 +279,53 @@ __global__ void gate_mix_bwd_kernel(T* dU, T* dA, T* dlogits, const T* dout, con
   }
 }
 
+// 16-byte vector forms: LPR = C / W consecutive lanes own one pixel row (LPR a power of two <= 64, so rows never straddle a wave)
+template <typename T>
+__global__ void gate_mix_fwd_vec_kernel(T* out, float* gate, const T* logits, const T* U, const T* A, int lpr, long nvec) {
+  constexpr int W = VT<T>::W;
+  const float k = 0.70710678118654752f;
+  GRID_STRIDE(v, nvec) {
+    const long r = v / lpr;
+    const float l0 = to_f(logits[2 * r]), l1 = to_f(logits[2 * r + 1]);
+    const float m = fmaxf(l0, l1);
+    const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+    if (v - r * lpr == 0) { gate[2 * r] = g0; gate[2 * r + 1] = g1; }
+    float u[W], a[W];
+    vload<T>(u, U + v * W); vload<T>(a, A + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) u[j] = k * (u[j] + g0 * u[j] + g1 * a[j]);
+    vstore<T>(out + v * W, u);
+  }
+}
+template <typename T>
+__global__ void gate_mix_bwd_vec_kernel(T* dU, T* dA, T* dlogits, const T* dout, const float* dgate, const float* gate,
+                                        const T* U, const T* A, int lpr, long nvec, long nvec_pad) {
+  constexpr int W = VT<T>::W;
+  const float k = 0.70710678118654752f;
+  // nvec_pad is a multiple of 64: every lane of a wave takes part in the shuffles (tail lanes carry zeros)
+  GRID_STRIDE(v, nvec_pad) {
+    const long r = v / lpr;
+    const bool ok = v < nvec;
+    float g0 = 0.f, g1 = 0.f, d0 = 0.f, d1 = 0.f;
+    if (ok) {
+      g0 = gate[2 * r]; g1 = gate[2 * r + 1];
+      float go[W], u[W], a[W];
+      vload<T>(go, dout + v * W); vload<T>(u, U + v * W); vload<T>(a, A + v * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) { go[j] *= k; d0 += go[j] * u[j]; d1 += go[j] * a[j]; u[j] = go[j] * (1.f + g0); a[j] = go[j] * g1; }
+      vstore<T>(dU + v * W, u); vstore<T>(dA + v * W, a);
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+    if (ok && v - r * lpr == 0) {
+      if (dgate) { d0 += dgate[2 * r]; d1 += dgate[2 * r + 1]; }
+      const float dot = d0 * g0 + d1 * g1;
+      dlogits[2 * r] = from_f<T>(g0 * (d0 - dot));
+      dlogits[2 * r + 1] = from_f<T>(g1 * (d1 - dot));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- row softmax for tiny C (Scaling_router, model_components.py:64)
 __global__ void softmax_rows_fwd_kernel(float* out, const float* x, int C, float scale, long rows) {
   GRID_STRIDE(r, rows) {
@@ -739,12 +786,22 @@ int hdmoe_lerp_param_bwd(void* da, void* db, float* dalpha, const void* g, const
 }
 int hdmoe_gate_mix_fwd(void* out, float* gate, const void* logits, const void* U, const void* A, long rows, int C,
                        int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(gate_mix_fwd_kernel<T>, rows * C, (T*)out, gate, (const T*)logits, (const T*)U, (const T*)A, C, rows))
+  DT_SWITCH(dtype, {
+    const int lpr = C / VT<T>::W;
+    if (C % VT<T>::W == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && al16(out) && al16(U) && al16(A))
+      L1D(gate_mix_fwd_vec_kernel<T>, rows * lpr, (T*)out, gate, (const T*)logits, (const T*)U, (const T*)A, lpr, rows * lpr);
+    else L1D(gate_mix_fwd_kernel<T>, rows * C, (T*)out, gate, (const T*)logits, (const T*)U, (const T*)A, C, rows);
+  })
 }
 int hdmoe_gate_mix_bwd(void* dU, void* dA, void* dlogits, const void* dout, const float* dgate, const float* gate,
                        const void* U, const void* A, long rows, int C, int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(gate_mix_bwd_kernel<T>, rows, (T*)dU, (T*)dA, (T*)dlogits, (const T*)dout, dgate, gate,
-                       (const T*)U, (const T*)A, C, rows))
+  DT_SWITCH(dtype, {
+    const int lpr = C / VT<T>::W;
+    if (C % VT<T>::W == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && al16(dU) && al16(dA) && al16(dout) && al16(U) && al16(A))
+      L1D(gate_mix_bwd_vec_kernel<T>, (rows * lpr + 63) / 64 * 64, (T*)dU, (T*)dA, (T*)dlogits, (const T*)dout, dgate, gate, (const T*)U,
+          (const T*)A, lpr, rows * lpr, (rows * lpr + 63) / 64 * 64);
+    else L1D(gate_mix_bwd_kernel<T>, rows, (T*)dU, (T*)dA, (T*)dlogits, (const T*)dout, dgate, gate, (const T*)U, (const T*)A, C, rows);
+  })
 }
 int hdmoe_softmax_rows_fwd(float* out, const float* x, long rows, int C, float scale, hipStream_t stream) {
   L1D(softmax_rows_fwd_kernel, rows, out, x, C, scale, rows);
