@@ -689,8 +689,11 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
     // [64 px][NB + pad] and streams it out as 16 B per lane, consecutive lanes covering whole pixel rows.
     constexpr int ROW = NB + VW;                             // elements; +16 B keeps the rows off each other's banks
     constexpr int PPR = NB / VW;                             // 16-B pieces per pixel row
+    constexpr int PXI = 64 / PPR;                            // pixel rows per store instruction
     __syncthreads();                                         // every wave is done reading the operand tiles
-    T* sE = reinterpret_cast<T*>(smem_raw) + wave * 64 * ROW;
+    T* sE = reinterpret_cast<T*>(smem_raw) + wave * 32 * ROW;   // one 32-pixel slab per wave, reused for each m-fragment
+    const int piece = lane % PPR, prow = lane / PPR;
+    const int cch = nbase + piece * VW;
 #pragma unroll
     for (int m = 0; m < CV2_MT; ++m) {
       const int q = wave * (32 * CV2_MT) + m * 32 + r;
@@ -710,22 +713,21 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
           }
           QT o;
           o[0] = from_f<T>(v0); o[1] = from_f<T>(v1); o[2] = from_f<T>(v2); o[3] = from_f<T>(v3);
-          *reinterpret_cast<QT*>(sE + (32 * m + r) * ROW + cl + 4 * h) = o;
+          *reinterpret_cast<QT*>(sE + r * ROW + cl + 4 * h) = o;
         }
-    }
-    // the slab is private to the wave: LDS operations of one wave complete in order, no workgroup barrier needed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps the compiler from hoisting the reads over the writes)
-    const int piece = lane % PPR, prow = lane / PPR;
-    const int cch = nbase + piece * VW;
+      // the slab is private to the wave: LDS operations of one wave complete in order, no workgroup barrier needed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps the compiler from hoisting the reads over the writes)
 #pragma unroll
-    for (int j = 0; j < PPR; ++j) {
-      const int pl = j * (64 / PPR) + prow;                  // pixel within the wave's 64
-      const int q = wave * 64 + pl;
-      const long lin = lin0 + q;
-      if (q < qlim && lin < HWo && cch < a.Cstore) {
-        const uint4 v = *reinterpret_cast<const uint4*>(sE + pl * ROW + piece * VW);
-        *reinterpret_cast<uint4*>(y + lin * a.Cstore + cch) = v;
+      for (int j = 0; j < 32 / PXI; ++j) {
+        const int pl = j * PXI + prow;                       // pixel within the 32 of this m-fragment
+        const int q2 = wave * (32 * CV2_MT) + m * 32 + pl;
+        const long lin2 = lin0 + q2;
+        if (q2 < qlim && lin2 < HWo && cch < a.Cstore) {
+          const uint4 v = *reinterpret_cast<const uint4*>(sE + pl * ROW + piece * VW);
+          *reinterpret_cast<uint4*>(y + lin2 * a.Cstore + cch) = v;
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next fragment overwrites the slab
     }
   } else {
 #pragma unroll
@@ -1228,8 +1230,8 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
       static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
       const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
       if (lds3 <= 64 * 1024 && v5ok) {
-        // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 64 px x (32 NT + pad) elements
-        const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 64 * (32 * NT + 16 / esz) * esz <= lds3;
+        // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 32 px x (32 NT + pad) elements
+        const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 32 * (32 * NT + 16 / esz) * esz <= lds3;
 #define CV5_LAUNCH(TT, NTv)                                                                                                              \
   do { if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);  \
        else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); } while (0)

@@ -86,12 +86,19 @@ def advance_seed(device) -> None:
 # Optional per-launch timing of the GEMM-shaped kernels (bench.py's roofline leg): when PROFILE is a list, every
 # hdmoe_conv_fwd / hdmoe_conv_wgrad launch is bracketed by events on the launch stream and logged with its shape.
 PROFILE = None
+_spacer = None
 
 
 def _timed(kind: str, info: dict, name: str, *args):
     if PROFILE is None:
         call(name, *args)
         return
+    # An event pair also spans the time the stream sits idle waiting for the host to enqueue the kernel.  A spacer launch in
+    # front keeps the GPU busy while start event, kernel and end event are all enqueued, so the pair brackets the kernel alone.
+    global _spacer
+    if _spacer is None:
+        _spacer = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    _spacer.zero_()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     call(name, *args)
@@ -115,7 +122,7 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
             tg -= 1
         lds3 = 80 * (halo + tg * max(kws) * 32 * nt)
         if I == cphys and Cstore % 4 == 0 and lds3 <= 64 * 1024:
-            lepi = Cstore % (16 // esz) == 0 and 4 * 64 * (32 * nt + 16 // esz) * esz <= lds3
+            lepi = Cstore % (16 // esz) == 0 and 4 * 32 * (32 * nt + 16 // esz) * esz <= lds3
             fwd_name = f"conv_fwd5_kernel<{tname}, {nt}, {'true' if lepi else 'false'}>"
         else:
             fwd_name = f"conv_fwd3_kernel<{tname}, {nt}>"
@@ -125,7 +132,19 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
         nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
         fwd_name = f"conv_fwd_kernel<{tname}, {nb}, {'true' if vec else 'false'}>"
     return dict(dtype=str(x.dtype).replace("torch.", ""), seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)],
-                fwd_name=fwd_name, wgrad_name=f"conv_wgrad2_kernel<{tname}, *> ({len(set(zip(khs, kws)))} launch(es) per call)")
+                fwd_name=fwd_name, wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws)))))
+
+
+def _wgrad_name(tname, O, tap_classes):
+    """Kernel instantiation(s) hdmoe_conv_wgrad picks (mirrors csrc/conv.hip: one launch per kernel-size class)."""
+    names = []
+    for taps in tap_classes:
+        mt = taps if taps < 4 else (taps + 3) // 4
+        ot = 1 if (mt > 7 or O <= 32) else 2
+        names.append(f"{ot}, {3 if mt <= 3 else (7 if mt <= 7 else 13)}")
+    if len(names) == 1:
+        return f"conv_wgrad2_kernel<{tname}, {names[0]}, true>"
+    return f"conv_wgrad2_kernel<{tname}, {{{' | '.join(names)}}}, true> ({len(names)} launches per call)"
 
 
 def _kernel_hw(w: Tensor):
