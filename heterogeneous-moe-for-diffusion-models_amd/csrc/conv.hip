@@ -870,7 +870,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // The contraction runs over PIXELS, so both MFMA operands need 8 consecutive pixels of one channel per lane while the
 // tiles are stored [pixel][channel]: bf16 uses the hardware transposing read ds_read_b64_tr_b16 (two per fragment,
 // cdna_hip_programming.md T10), fp32 reads its single value per 32x32x2 MFMA with conflict-free ds_read_b32.
-constexpr int WG2_PT = 128;     // pixels per tile
+constexpr int WG2_PT = 128;     // pixels per tile (bf16)
+// f32 holds twice the bytes per staged pixel in registers (next unit's prefetch) and per accumulator operand: 64-pixel tiles
+// keep the f32 instantiations under 256 VGPRs without spills (spill reloads in the k-loop wait on the prefetch loads).
+template <typename T> struct Wg2PT { static constexpr int N = sizeof(T) == 4 ? 64 : 128; };
 constexpr int WG2_IB = 32;      // input channels per workgroup
 
 template <typename T> DEVI void frag_set_raw(Frag8<T>& f, int j, T v);
@@ -905,8 +908,9 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   constexpr int VW = VecW<T>::N;
   constexpr int CPP = OB / VW;                                          // 16-B chunks per dy pixel
   constexpr int XPP = WG2_IB / VW;                                      // 16-B chunks per x pixel
-  T* sdy = reinterpret_cast<T*>(smem_raw);                              // [WG2_PT][OBP]
-  T* sx = sdy + WG2_PT * OBP;                                           // [halo rows][halo cols][WG2_IB]
+  constexpr int PT = Wg2PT<T>::N;
+  T* sdy = reinterpret_cast<T*>(smem_raw);                              // [PT][OBP]
+  T* sx = sdy + PT * OBP;                                           // [halo rows][halo cols][WG2_IB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int q4 = (lane & 15) >> 2, col4 = (lane & 16) + 4 * (lane & 3);  // tr-read row within the 4-row block / column
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   auto div_tw = [&](int q) { return tw_shift >= 0 ? (q >> tw_shift) : q / TW; };
   auto fast_div = [](int q, int magic) { return (int)(((unsigned)q * (unsigned)magic) >> 20); };
 
-  for (int e = tid; e < (WG2_PT - TH * TW) * OBP; e += 256) sdy[TH * TW * OBP + e] = zero;   // rows no tile ever writes
+  for (int e = tid; e < (PT - TH * TW) * OBP; e += 256) sdy[TH * TW * OBP + e] = zero;   // rows no tile ever writes
 
   int toff[MAXT];                                             // LDS offset of this wave's taps inside the halo tile
 #pragma unroll
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
 #pragma unroll
     for (int q = 0; q < OT; ++q) acc[t][q] = (f32x16)(0.f);
 
-  constexpr int NDY = (WG2_PT * CPP + 255) / 256;
+  constexpr int NDY = (PT * CPP + 255) / 256;
   constexpr int NX = sizeof(T) == 2 ? 6 : 8;                  // halo chunks per thread held in registers (host checks the cap)
   uint4 rdy[VEC ? NDY : 1], rx[VEC ? NX : 1];
   // unit -> (sample, tile origin); large unit indices (flattened linear layers) take the exact division
@@ -1283,8 +1287,9 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels); one launch per kernel-size class so the
     //      per-wave accumulator count (MAXT) matches the class (3x3 -> 3, 5x5 -> 7, 7x7 -> 13)
     Wg2Geom gm;
-    gm.TW = Wo < WG2_PT ? Wo : WG2_PT;
-    gm.TH = WG2_PT / gm.TW; if (gm.TH > Ho) gm.TH = Ho; if (gm.TH < 1) gm.TH = 1;
+    const int PTpx = dtype == HDMOE_F32 ? Wg2PT<float>::N : Wg2PT<bf16>::N;
+    gm.TW = Wo < PTpx ? Wo : PTpx;
+    gm.TH = PTpx / gm.TW; if (gm.TH > Ho) gm.TH = Ho; if (gm.TH < 1) gm.TH = 1;
     gm.tw_shift = -1;
     for (int sft = 0; sft < 8; ++sft) if ((1 << sft) == gm.TW) gm.tw_shift = sft;
     gm.tiles_y = cdiv(Ho, gm.TH); gm.tiles_x = cdiv(Wo, gm.TW);
@@ -1299,7 +1304,7 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
       const int mt = taps < 4 ? taps : (taps + 3) / 4;
       const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
       const int OBP = (OT == 2 && esz == 2) ? 96 : 32 * OT;
-      const size_t lds = (size_t)esz * (WG2_PT * OBP + (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1) * WG2_IB);
+      const size_t lds = (size_t)esz * (PTpx * OBP + (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1) * WG2_IB);
       if (lds > 64 * 1024 || mt > 13) ok = false;
     }
     if (ok) {
@@ -1313,7 +1318,7 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
         const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
         const int OB = 32 * OT, OBP = (OT == 2 && esz == 2) ? OB + 32 : OB;
         const int halo = (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1);
-        const size_t lds = (size_t)esz * (WG2_PT * OBP + halo * WG2_IB);
+        const size_t lds = (size_t)esz * (PTpx * OBP + halo * WG2_IB);
         const int nx_cap = (esz == 2 ? 6 : 8) * 256;                    // register-prefetch capacity (16-B halo chunks)
         const bool vec = Cout % vw == 0 && Cphys % vw == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 &&
                          halo * (WG2_IB / vw) <= nx_cap;
