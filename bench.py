@@ -142,7 +142,7 @@ def roofline_leg(step_fn, n_steps):
                 method="HIP events around each launch on the launch stream, a spacer launch in front keeps host enqueue gaps out and the event-pair overhead measured on a trivial launch is subtracted; see profiles/", event_overhead_us=round(1e3 * overhead, 2)), table
 
 
-def cpu_baseline(cfg_id, kw, module, seconds=15.0):
+def cpu_baseline(cfg_id, kw, module, seconds=12.0):
     """The CPU oracle (port of the reference algorithm) timed on the host cores on a bounded sample: B = 8 samples per
     step, eval-mode fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
     from oracle import hdmoe_oracle as O
@@ -183,7 +183,7 @@ def cpu_baseline(cfg_id, kw, module, seconds=15.0):
             v.grad = None
         times.append(time.time() - t0)
         print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
-        if len(times) >= 8:
+        if len(times) >= 40:
             break
     med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
     return med, B, cores, len(times)
