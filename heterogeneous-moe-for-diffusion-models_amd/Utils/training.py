@@ -76,7 +76,7 @@ class Trainer:
     generation, fused loss, flat-bucket gradient all-reduce, fused clip + AdamW)."""
 
     def __init__(self, model, model_config, optim_config, loss_config, mask_config, zeta_config, max_grad_norm: float = 1.0,
-                 fuse_clip_into_step: bool = True):
+                 fuse_clip_into_step: bool = True, logger=None):
         self.model, self.cfg, self.mask_cfg = model, model_config, mask_config
         self.optimizer = build_optimizer(model, optim_config)
         self.scheduler = build_scheduler(self.optimizer, optim_config)
@@ -93,6 +93,7 @@ class Trainer:
                                   prior_bal=loss_config["prior_bal"])
         self.buckets = GradBuckets(model)                    # .grad become views of flat fp32 buckets (all-reduced when world > 1)
         self.max_grad_norm, self.fuse = float(max_grad_norm), fuse_clip_into_step
+        self.logger = logger                                 # graphs.logger.Logger (sync-free) or None
         self._clip_params = [p for p in model.parameters()]
         self.step_idx = 0
 
@@ -106,9 +107,20 @@ class Trainer:
                                Vit_router_mask=self.vit_mask_gen(sigma=sigma, step=step), zeta=self.zeta_sched.get_zeta(step=step),
                                transition_point=mc["p_mean"], softness=mc["p_std"], return_log_var=True)
         loss = self.criterion(sigma_vec=sigma, x=latent_images, sigma=sigma, out_model=out_model)
+        lg = self.logger
+        if lg is not None:                                   # same calls, same order as reference training.py:160-188
+            lg.log_training_step(step=step, loss_dict=loss, zeta=self.zeta_sched.get_zeta(step=step),
+                                 log_var=out_model["log_var"] if out_model["log_var"] is not None else 0.0,
+                                 lr=self.optimizer.param_groups[0]["lr"], sigma=sigma, p_mean=mc["p_mean"], p_std=mc["p_std"])
+            lg.log_router_statistics(step=step, unet_probs=out_model["Unet_router_loss"], vit_probs=out_model["vit_router_loss"],
+                                     sigma=sigma, p_mean=mc["p_mean"], p_std=mc["p_std"])
+            lg.log_scaling_gating(scaling_factors=out_model["scaling_net_out"], gate_weights=out_model["out_gate"], sigma=sigma)
         self.buckets.zero_grad()
         loss["loss"].backward()
         self.buckets.finish()
+        if lg is not None:
+            lg.log_gradients(step=step, model=self.model.net)
+            lg.log_weight_statistics(step=step, model=self.model.net)
         from hdmoe_hip.optim import clip_grad_norm_
         if self.fuse:
             self.optimizer.step(clip=(self._clip_params, self.max_grad_norm))

@@ -325,14 +325,64 @@ def wide_model(cfg_id, B, seed):
           f"V {float(margin['vit_raw'].min()):.4f} |denoised| {float(out['denoised'].abs().max()):.3f}")
 
 
+def logger_fixture():
+    """Records written by the reference's graphs/logger.py for a seeded 25-step stream (row N4)."""
+    import json, tempfile
+    sys.path.insert(0, os.path.join(REF, "graphs"))
+    import logger as rlog                                # noqa: E402  (reference graphs/logger.py)
+    gen = torch.Generator().manual_seed(31)
+    B, E = 12, 4
+    steps = []
+    for step in range(25):
+        sigma = torch.exp(torch.randn(B, generator=gen) * 1.6 - 1.2)
+        loss = {k: torch.rand((), generator=gen) for k in ("loss", "denoising", "pure_loss", "balance", "z_loss", "entropy")}
+        steps.append(dict(step=step, loss=loss, zeta=0.1 + 0.01 * step, log_var=float(torch.randn((), generator=gen)),
+                          lr=1e-3 * (1 - step / 50), sigma=sigma,
+                          unet_probs=torch.softmax(3 * torch.randn(B, E, generator=gen), -1),
+                          vit_probs=torch.softmax(torch.randn(B, E, generator=gen), -1),
+                          scaling=2 * torch.softmax(torch.randn(B, 2, generator=gen), -1),
+                          gate=torch.softmax(torch.randn(B, 2, generator=gen), -1)))
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.Unet_experts = torch.nn.ModuleList([torch.nn.Conv2d(3, 5, 3) for _ in range(2)])
+            self.VIT_experts = torch.nn.ModuleList([torch.nn.Linear(7, 4) for _ in range(3)])
+            self.Unet_router = torch.nn.Linear(6, 4)
+            self.vit_router = torch.nn.Linear(6, 4)
+            self.cross_attn = torch.nn.Linear(5, 5)
+    torch.manual_seed(17)
+    net = Net()
+    grads = [[torch.randn(p.shape, generator=gen) for p in net.parameters()] for _ in range(25)]
+    with tempfile.TemporaryDirectory() as d:
+        lg = rlog.Logger(log_dir=d, run_name="fx", log_interval=10)
+        for st, gs in zip(steps, grads):
+            for p, g in zip(net.parameters(), gs):
+                p.grad = g.clone()
+            lg.log_training_step(step=st["step"], loss_dict=st["loss"], zeta=st["zeta"], log_var=st["log_var"], lr=st["lr"],
+                                 sigma=st["sigma"], p_mean=-1.2, p_std=1.6)
+            lg.log_router_statistics(step=st["step"], unet_probs=st["unet_probs"], vit_probs=st["vit_probs"], sigma=st["sigma"],
+                                     p_mean=-1.2, p_std=1.6)
+            lg.log_scaling_gating(scaling_factors=st["scaling"], gate_weights=st["gate"], sigma=st["sigma"])
+            lg.log_gradients(step=st["step"], model=net)
+            lg.log_weight_statistics(step=st["step"], model=net)
+        files = {k: [json.loads(l) for l in open(getattr(lg, k))] for k in
+                 ("main_log_file", "router_log_file", "gradient_log_file", "weight_log_file")}
+    torch.save(dict(steps=steps, grads=grads, net_state=sd(net), files=files), os.path.join(OUT, "logger.pt"))
+    print("logger:", {k: len(v) for k, v in files.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if "--logger-only" in sys.argv:
+        logger_fixture()
+        sys.exit(0)
     if "--wide-only" not in sys.argv:
         components()
         full_model(1)
         full_model(2)
+        logger_fixture()
     wide_model(2, 4, 21)
     wide_model(3, 4, 32)
     wide_model(4, 2, 23)

@@ -751,13 +751,20 @@ def test_trainer_iteration_and_checkpoint_roundtrip(tmp_path):
         for n, p in model.named_parameters():
             if n.endswith("out_gain"):
                 p.fill_(0.5)
-    tr = training.Trainer(model, mcfg, configs.optim_configs, configs.loss_configs, configs.mask_configs, configs.zeta_configs)
+    from graphs.logger import Logger
+    lg = Logger(log_dir=str(tmp_path / "logs"), run_name="t", log_interval=2)
+    tr = training.Trainer(model, mcfg, configs.optim_configs, configs.loss_configs, configs.mask_configs, configs.zeta_configs, logger=lg)
     gen = torch.Generator(device=DEV).manual_seed(1)
     batches = [(0.5 * torch.randn(6, 4, 16, 16, device=DEV, generator=gen), torch.randn(6, 5, 32, device=DEV, generator=gen)) for _ in range(3)]
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     seen = []
     training.train_steps(tr, batches, on_step=lambda s, r: seen.append(float(r["loss"]["loss"])))
     assert len(seen) == 3 and all(math.isfinite(v) for v in seen)
+    import json
+    main_rec = [json.loads(l) for l in open(lg.main_log_file)]
+    assert [r["step"] for r in main_rec] == [0, 2] and all(math.isfinite(r["loss"]) and "gate_wx" in r for r in main_rec[1:])
+    grad_rec = [json.loads(l) for l in open(lg.gradient_log_file)]
+    assert len(grad_rec) == 2 and grad_rec[0]["Unet_experts_grad_norm"] > 0 and "cross_attn_grad_norm" in grad_rec[0]
     moved = [n for n, p in model.named_parameters() if not torch.equal(p, before[n])]
     assert any("Unet_experts" in n for n in moved) and any("vit_router" in n for n in moved)
     assert abs(tr.optimizer.param_groups[1]["lr"] - configs.optim_configs["lr_vit"]) < 1e-3 * configs.optim_configs["lr_vit"]
