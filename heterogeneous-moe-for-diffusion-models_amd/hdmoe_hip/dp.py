@@ -20,7 +20,9 @@ class GradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()                                           # backward produces gradients roughly in this order
-        cap = int(bucket_mb * (1 << 20) / 4)
+        from . import ops as _ops
+        # with side streams every bucket goes out from finish() anyway (see `eager` below): one flat bucket = one collective
+        cap = int(bucket_mb * (1 << 20) / 4) if not _ops.SIDE_STREAMS else (1 << 62)
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
         cur, n = [], 0
@@ -39,7 +41,6 @@ class GradBuckets:
         # Hooks fire on whatever stream the gradient was produced on.  With the ViT experts forked onto side streams a bucket can
         # be completed on one stream while another still writes a neighbouring slice, so eager launches are only safe when the
         # whole step runs on one stream; otherwise every bucket goes out in finish(), after autograd has joined the streams.
-        from . import ops as _ops
         self.eager = not _ops.SIDE_STREAMS
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         for bi, members in enumerate(self._members):

@@ -35,13 +35,18 @@ class _Toy(torch.nn.Module):
         return self.head(out)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, side_streams):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hdmoe_hip import ops
     from hdmoe_hip.dp import GradBuckets
+    ops.SIDE_STREAMS = side_streams
     model = _Toy()
     buckets = GradBuckets(model, bucket_mb=0.0005)          # tiny buckets -> several, exercised out of order
-    assert len(buckets.buckets) > 2
+    if side_streams:                                        # multi-stream steps: one flat bucket, reduced from finish()
+        assert len(buckets.buckets) == 1 and not buckets.eager
+    else:                                                   # single-stream steps: bucketed, launched from autograd hooks in order
+        assert len(buckets.buckets) > 2 and buckets.eager
     assert all(p.grad is not None and p.grad.data_ptr() >= b.data_ptr() for b in buckets.buckets[:1] for p in buckets._members[0])
     g = torch.Generator().manual_seed(10 + rank)
     res = []
@@ -76,11 +81,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_grad_buckets_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("side_streams", [False, True])
+def test_grad_buckets_world2_gloo(side_streams):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, side_streams)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
