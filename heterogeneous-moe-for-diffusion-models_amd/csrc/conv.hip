@@ -1335,7 +1335,10 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
             upw = (class_units + parts - 1) / parts;
         } else {
             static const long bf16_parts = getenv("HDMOE_WG_PARTS") ? atol(getenv("HDMOE_WG_PARTS")) : 384;
-            long parts = bf16_parts / ((long)ibs * obs); if (parts < 8) parts = 8;
+            // classes with more than 9 taps flush (taps x 64 x 32) floats per workgroup: fewer, longer workgroups (bench sweep:
+            // 384 -> 256 partitions = -0.7 ms/step at B = 256)
+            static const long bf16_parts_big = getenv("HDMOE_WG_PARTS_BIG") ? atol(getenv("HDMOE_WG_PARTS_BIG")) : 256;
+            long parts = (taps > 9 ? bf16_parts_big : bf16_parts) / ((long)ibs * obs); if (parts < 8) parts = 8;
             upw = (units_l + parts - 1) / parts;
         }
         if (upw < 1) upw = 1;
