@@ -1330,7 +1330,8 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
         // once.  bf16 units are short and the flush dominates: fewer, longer workgroups measured best (launch_table sweeps).
         long upw;
         if (esz == 4) {
-            long parts = 512 / ((long)ibs * obs); if (parts < 8) parts = 8;
+            static const long f32_parts = getenv("HDMOE_WG_PARTS_F32") ? atol(getenv("HDMOE_WG_PARTS_F32")) : 512;
+            long parts = f32_parts / ((long)ibs * obs); if (parts < 8) parts = 8;
             const long class_units = (units_l * gm.ngr + ngroups - 1) / ngroups;   // assume balanced routing
             upw = (class_units + parts - 1) / parts;
         } else {
