@@ -941,10 +941,15 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
 
   for (int e = tid; e < (PT - TH * TW) * OBP; e += 256) sdy[TH * TW * OBP + e] = zero;   // rows no tile ever writes
 
+  // Tap ownership.  Dealing 9 taps round-robin gives the waves 3/2/2/2 and three of them idle a third of every k-loop at the
+  // barrier.  For 3x3 layers wave w instead owns taps 2w and 2w+1 outright and every 4th k-step (ks % 4 == w) of tap 8:
+  // 9 tap-k-steps per 4 k-steps for every wave, still three accumulator sets per wave (tap 8 is flushed as four partials).
+  const bool bal9 = ntaps == 9 && MAXT == 3 && sizeof(T) == 4;   // (bf16: measured slower, its k-loop is not MFMA-bound)
+  auto tap_of = [&](int t) { return split_k ? t : (bal9 ? (t < 2 ? 2 * wave + t : 8) : wave + 4 * t); };
   int toff[MAXT];                                             // LDS offset of this wave's taps inside the halo tile
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int tap = split_k ? t : wave + 4 * t;
+    const int tap = tap_of(t);
     const int ky = tap / kw, kx = tap - ky * kw;
     toff[t] = (ky * HWp + kx) * WG2_IB;
   }
@@ -1084,8 +1089,8 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
         const T* xb = sx + (tyb * HWp + (qbc - tyb * TW)) * WG2_IB;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-          const int tap = split_k ? t : wave + 4 * t;
-          if (tap < ntaps) {
+          const int tap = tap_of(t);
+          if (tap < ntaps && !(bal9 && t == 2 && (ks & 3) != wave)) {
             Frag8<T> fb;
             load_frag_tr(fb, xa + toff[t], xb + toff[t], col4);
 #pragma unroll
@@ -1106,8 +1111,8 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
         }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-          const int tap = split_k ? t : wave + 4 * t;
-          if (tap < ntaps) {
+          const int tap = tap_of(t);
+          if (tap < ntaps && !(bal9 && t == 2 && (ks & 3) != wave)) {
             Frag8<T> fb;
 #pragma unroll
             for (int j = 0; j < 8; ++j) frag_set_raw<T>(fb, j, sx[qs[j] + toff[t]]);
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   const int ci = i0 + r;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int tap = split_k ? t : wave + 4 * t;
+    const int tap = tap_of(t);
     if (tap < ntaps) {
 #pragma unroll
       for (int q = 0; q < OT; ++q) {
