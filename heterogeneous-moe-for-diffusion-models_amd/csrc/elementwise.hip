@@ -586,6 +586,55 @@ __global__ __launch_bounds__(256) void seq_reduce_vec_kernel(float* out, const T
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(long)s * C + c], scale * sm[c]);
 }
+// Deterministic forms (no atomics: the router's average pool feeds the top-k, and run-to-run float-add order would make the
+// logits -- and through bf16 rounding every downstream tensor -- differ between identical calls).
+// (a) one block per sample; thread (r, c) = (tid / cv, tid % cv) walks rows r, r + R, ... of its 16-byte channel chunk, then a
+//     fixed-order tree over the R = 256 / cv row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void seq_reduce_det_vec_kernel(float* out, const T* x, long S, int C, float scale) {
+  constexpr int W = VT<T>::W;
+  extern __shared__ float sm[];                                // [R][C]
+  const int n = blockIdx.x, cv = C / W, R = 256 / cv;
+  const int r = threadIdx.x / cv, c0 = (threadIdx.x % cv) * W;
+  const T* xs = x + (long)n * S * C;
+  float acc[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc[j] = 0.f;
+  for (long s0 = r; s0 < S; s0 += R) {
+    float f[W];
+    vload<T>(f, xs + s0 * C + c0);
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) sm[r * C + c0 + j] = acc[j];
+  __syncthreads();
+  for (int st = R >> 1; st >= 1; st >>= 1) {
+    if (r < st) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) sm[r * C + c0 + j] += sm[(r + st) * C + c0 + j];
+    }
+    __syncthreads();
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) out[(long)n * C + c0 + j] += scale * sm[c0 + j];
+  }
+}
+// (b) any C: one thread per (sample, channel), four interleaved partial sums combined in a fixed order
+template <typename T>
+__global__ void seq_reduce_det_kernel(float* out, const T* x, long S, int C, float scale) {
+  const int n = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const T* xs = x + (long)n * S * C + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  long s0 = 0;
+  for (; s0 + 4 <= S; s0 += 4) {
+    a0 += to_f(xs[s0 * C]); a1 += to_f(xs[(s0 + 1) * C]); a2 += to_f(xs[(s0 + 2) * C]); a3 += to_f(xs[(s0 + 3) * C]);
+  }
+  for (; s0 < S; ++s0) a0 += to_f(xs[s0 * C]);
+  out[(long)n * C + c] += scale * ((a0 + a1) + (a2 + a3));
+}
 template <typename T> static inline bool chunk_fixed_ok(int C) {
   const int W = VT<T>::W;
   return C % W == 0 && C / W <= 256 && 256 % (C / W) == 0;
@@ -756,11 +805,11 @@ int hdmoe_upsample2(void* out, const void* x, int N, int Ho, int Wo, int C, floa
 }
 int hdmoe_seq_reduce(float* out, const void* x, int N, long S, int C, float scale, int dtype, hipStream_t stream) {
   if (N > 65535 || C > 8192) return HDMOE_EINVAL;
-  const int chunk = 64;
-  dim3 grid(cdiv(S, chunk), N);
-  DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(x)) hipLaunchKernelGGL(seq_reduce_vec_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x, S, C, scale, chunk);
-                   else hipLaunchKernelGGL(seq_reduce_kernel<T>, grid, dim3(TPB), C * sizeof(float), stream, out, (const T*)x,
-                                      S, C, scale, chunk))
+  // accumulates into `out` (callers pass zeros or a running sum); deterministic: no atomics, fixed summation order
+  DT_SWITCH(dtype, if (chunk_fixed_ok<T>(C) && al16(x)) hipLaunchKernelGGL(seq_reduce_det_vec_kernel<T>, dim3(N), dim3(256),
+                                                                           (size_t)(256 / (C / VT<T>::W)) * C * sizeof(float), stream,
+                                                                           out, (const T*)x, S, C, scale);
+                   else hipLaunchKernelGGL(seq_reduce_det_kernel<T>, dim3(cdiv(C, TPB), N), dim3(TPB), 0, stream, out, (const T*)x, S, C, scale))
 }
 int hdmoe_seq_bcast_add(void* out, const void* x, const float* t, int N, long S, int C, float scale, int dtype,
                         hipStream_t stream) {

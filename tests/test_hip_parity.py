@@ -844,3 +844,54 @@ def test_graph_replay_with_side_streams_matches_single_stream_eager():
                 bad.append((n, err, scale))
     assert not bad, bad[:5]
     assert len(ref) > 400
+
+
+def test_full_size_batch_independence_and_router_invariants():
+    """BASELINE config 2 at its FULL size (B = 256, bf16 experts, 4x32x32 latents, text 77x768), through properties that do not
+    need the oracle at that size: routing is per sample, so a sample's output (bit for bit) and input-gradient must not depend
+    on which other samples share its batch (full batch == two half batches, which exercise different expert-row groupings,
+    tile counts and flattened-row lengths); every router row has exactly k non-zero weights that sum to 1, zero weight on masked experts; nothing is NaN."""
+    import hdmoe_hip
+    from Utils import configs
+    from models import model_config1
+    from oracle.recipe import fill_state
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    try:
+        kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
+        model = model_config1.preconditioned_HDMOEM(**kw)
+        model.load_state_dict(fill_state(model.state_dict(), 77))
+        model = model.to(DEV).eval()
+        B, E, k = 256, kw["num_experts"], kw["top_k"]
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.randn(B, 4, 32, 32, device=DEV, generator=g)
+        sigma = torch.exp(torch.randn(B, 1, 1, 1, device=DEV, generator=g) * 1.6 - 1.2)
+        text = torch.randn(B, 77, 768, device=DEV, generator=g)
+        um = (torch.rand(B, E, device=DEV, generator=g) > 0.3).float(); um[:, :k] = 1.0
+        vm = (torch.rand(B, E, device=DEV, generator=g) > 0.3).float(); vm[:, -k:] = 1.0
+
+        def run(sl):
+            xi = x[sl].clone().requires_grad_(True)
+            out = model(x=xi, sigma=sigma[sl], text_emb=text[sl], Unet_router_mask=um[sl], Vit_router_mask=vm[sl], zeta=0.0,
+                        return_log_var=True)
+            out["denoised"].float().square().sum().backward()
+            return out, xi.grad
+
+        run(slice(0, 8))                                           # registers the weight bank: the three runs below all use it
+        full, gfull = run(slice(0, B))
+        h1, g1 = run(slice(0, B // 2))
+        h2, g2 = run(slice(B // 2, B))
+        for key in ("denoised", "Unet_raw", "vit_raw", "Unet_router_loss", "vit_router_loss", "out_gate", "log_var"):
+            a = full[key].detach().float()
+            b = torch.cat([h1[key].detach().float(), h2[key].detach().float()])
+            assert torch.isfinite(a[torch.isfinite(b)]).all(), key
+            assert torch.equal(a, b), key                           # forward is atomic-free: bit-identical per sample
+        close_scaled(gfull, torch.cat([g1, g2]), 1e-5, msg="x.grad")    # backward sums a few terms with float atomics
+        for key, mask in (("Unet_raw", um), ("vit_raw", vm)):
+            logits = full[key].detach().float()
+            assert bool(((logits == float("-inf")) == (mask == 0)).all()), key          # masked experts: -inf logits
+            idx = torch.topk(logits, k, dim=-1).indices
+            assert bool(mask.gather(1, idx).bool().all())                                # routed only to eligible experts
+        probs = full["Unet_router_loss"].detach().float()
+        assert torch.allclose(probs.sum(-1), torch.ones(B, device=DEV), atol=1e-5) and bool((probs[um == 0] == 0).all())
+    finally:
+        hdmoe_hip.set_compute_dtype(torch.float32)
