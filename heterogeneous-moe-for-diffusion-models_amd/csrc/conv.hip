@@ -7,10 +7,15 @@
 // range of group g (device memory, produced by the dispatch plan, so no host sync is needed).
 //
 // GEMM view (fwd and dgrad):  M = output pixels, N = output channels, K = taps * input channels.
-//   * each wave owns a 32-pixel x (32*NB)-channel tile; MFMA 32x32x16 (bf16) or 8x 32x32x2 (f32)
-//   * K is walked tap-major in 16-channel chunks; operands come from global memory as 16-B vectors
-// wgrad:  M = out channels, N = in channels, K = pixels, one tap per wave, fp32 atomics into a
-//   [tap][O][I] slab (contiguous I => full-rate atomic shape, MI355X_MICROARCH "Global float atomics").
+//   conv_fwd5_kernel  (default)   256-pixel x 32/64-channel workgroup tiles, halo + weight rows staged in LDS per
+//                                 (64-byte channel chunk, kernel-row group) stage, next stage prefetched into registers,
+//                                 MFMA 32x32x16 bf16 / 8x 32x32x2 f32, epilogue through LDS as 16-byte stores
+//   conv_fwd3_kernel              same walk with a per-tile staging plan; layers with a channel tail / implicit ones channel
+//   conv_fwd2_kernel, conv_fwd_kernel   earlier generations, kept for odd shapes (tiny images, stride > 1) and A/B runs
+// wgrad:  M = out channels, N = in channels, K = pixels.
+//   conv_wgrad2_kernel            pixel tile + halo in LDS, taps owned per wave, transposing LDS reads (bf16), one fp32 atomic
+//                                 flush per workgroup into a [tap][O][I] slab (contiguous I: full-rate atomic shape,
+//                                 MI355X_MICROARCH "Global float atomics"); conv_wgrad_kernel for stride > 1
 #include <stdlib.h>
 #include "common.h"
 #include "hdmoe.h"
