@@ -558,11 +558,11 @@ template <typename T> struct Quad;
 template <> struct Quad<bf16> { typedef bf16x4 type; };
 template <> struct Quad<float> { typedef f32x4 type; };
 
-template <typename T, int NT, bool LEPI>
+template <typename T, int NT, bool LEPI, int NHR>
 __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg) {
   constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16;
   constexpr int NB = 32 * NT, LNB = NT == 1 ? 5 : (NT == 2 ? 6 : 7);
-  constexpr int NWR = 9, NHR = 7;                           // 16-B pieces per thread held in registers (weights / halo)
+  constexpr int NWR = 9;                                    // 16-B weight pieces per thread held in registers (halo: NHR, 7 or 9)
   typedef typename Quad<T>::type QT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sA = reinterpret_cast<T*>(smem_raw);                    // [halo px][PSE]
@@ -1234,26 +1234,40 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     const size_t lds = (size_t)80 * (halo_cap + maxkw * 32 * NT);
     const bool vec = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
     dim3 grid(tiles_y * tiles_x, N, cdiv(Cstore, 32 * NT));
-    // v3 (register prefetch): rows of weights per stage <= 576 (9 chunks/thread), halo <= 448 px (7 chunks/thread)
-    if (vec && halo_cap * 4 <= 7 * 256 && maxkw * 32 * NT <= 576 && (long)maxkh * maxkw * Cout * Ipad < (1l << 26) &&
+    // v5 / v3 (register prefetch): rows of weights per stage <= 576 (9 chunks/thread); halo <= 448 px (7 chunks/thread), or for
+    // v5 <= 576 px (9 chunks/thread: 7x7 experts, whose halo of a 256-pixel tile is 14 x 38 or 22 x 22 pixels)
+    static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
+    const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
+    const int halo_max = v5ok ? 9 * 256 : 7 * 256;
+    if (vec && halo_cap * 4 <= halo_max && maxkw * 32 * NT <= 576 && (long)maxkh * maxkw * Cout * Ipad < (1l << 26) &&
         (long)H * W * Cphys < (1l << 30) && !getenv("HDMOE_CONV_V2")) {
+      // a workgroup may use up to 80 KB of LDS under v5 (two still share a CU): needed by 7x7 experts with 64-channel tiles
+      const size_t cap = v5ok ? 80 * 1024 : 64 * 1024;
       int tg = 576 / (maxkw * 32 * NT);
       if (tg > maxkh) tg = maxkh;
-      while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;
+      while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;       // prefer <= 64 KB
       const size_t lds3 = (size_t)80 * (halo_cap + tg * maxkw * 32 * NT);
-      static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
-      const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
-      if (lds3 <= 64 * 1024 && v5ok) {
+      if (lds3 <= cap && v5ok) {
+        static bool attr_set = false;
+        if (!attr_set) {                                     // opt every instantiation into > 64 KB of dynamic LDS, once
+          attr_set = true;
+#define CV5_ATTR(TT, NTv, L, H) (void)hipFuncSetAttribute((const void*)conv_fwd5_kernel<TT, NTv, L, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+#define CV5_ATTR4(TT, NTv) CV5_ATTR(TT, NTv, true, 7); CV5_ATTR(TT, NTv, false, 7); CV5_ATTR(TT, NTv, true, 9); CV5_ATTR(TT, NTv, false, 9)
+          CV5_ATTR4(float, 1); CV5_ATTR4(float, 2); CV5_ATTR4(bf16, 1); CV5_ATTR4(bf16, 2);
+        }
         // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 32 px x (32 NT + pad) elements
         const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 32 * (32 * NT + 16 / esz) * esz <= lds3;
-#define CV5_LAUNCH(TT, NTv)                                                                                                              \
-  do { if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);  \
-       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); } while (0)
+        const bool big_halo = halo_cap * 4 > 7 * 256;
+#define CV5_LAUNCH(TT, NTv)                                                                                                                        \
+  do { if (lepi && !big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);   \
+       else if (!big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); \
+       else if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);       \
+       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); } while (0)
         if (dtype == HDMOE_F32) { if (NT == 1) CV5_LAUNCH(float, 1); else CV5_LAUNCH(float, 2); }
         else { if (NT == 1) CV5_LAUNCH(bf16, 1); else CV5_LAUNCH(bf16, 2); }
         return hdmoe_launch_status();
       }
-      if (lds3 <= 64 * 1024) {
+      if (lds3 <= 64 * 1024 && halo_cap * 4 <= 7 * 256) {
         if (dtype == HDMOE_F32) {
           if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<float, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
           else hipLaunchKernelGGL((conv_fwd3_kernel<float, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);

@@ -116,16 +116,19 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
     nt = 1 if Cstore <= 32 else 2
     lds = 80 * ((th + max(khs) - 1) * (tw + max(kws) - 1) + max(kws) * 32 * nt)
     halo = (th + max(khs) - 1) * (tw + max(kws) - 1)
-    if Ho * Wo >= 64 and vec and halo * 4 <= 7 * 256 and max(kws) * 32 * nt <= 576:
+    v5ok = I == cphys and Cstore % 4 == 0
+    if Ho * Wo >= 64 and vec and halo * 4 <= (9 if v5ok else 7) * 256 and max(kws) * 32 * nt <= 576:
         tg = min(576 // (max(kws) * 32 * nt), max(khs))
         while tg > 1 and 80 * (halo + tg * max(kws) * 32 * nt) > 64 * 1024:
             tg -= 1
         lds3 = 80 * (halo + tg * max(kws) * 32 * nt)
-        if I == cphys and Cstore % 4 == 0 and lds3 <= 64 * 1024:
+        if v5ok and lds3 <= 80 * 1024:
             lepi = Cstore % (16 // esz) == 0 and 4 * 32 * (32 * nt + 16 // esz) * esz <= lds3
-            fwd_name = f"conv_fwd5_kernel<{tname}, {nt}, {'true' if lepi else 'false'}>"
-        else:
+            fwd_name = f"conv_fwd5_kernel<{tname}, {nt}, {'true' if lepi else 'false'}, {9 if halo * 4 > 7 * 256 else 7}>"
+        elif lds3 <= 64 * 1024 and halo * 4 <= 7 * 256:
             fwd_name = f"conv_fwd3_kernel<{tname}, {nt}>"
+        else:
+            fwd_name = f"conv_fwd2_kernel<{tname}, {nt}, {'true' if vec else 'false'}>"
     elif Ho * Wo >= 64 and lds <= 64 * 1024:
         fwd_name = f"conv_fwd2_kernel<{tname}, {nt}, {'true' if vec else 'false'}>"
     else:
