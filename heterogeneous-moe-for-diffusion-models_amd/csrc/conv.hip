@@ -769,7 +769,7 @@ struct WgradArgs {
   const void* dy;      // [N][Ho][Wo][Cout]
   float* G[HDMOE_MAX_GROUPS];   // [tap][Cout][Cin] fp32, pre-zeroed
   const int* seg;
-  int N, H, W, Ho, Wo, Cin, Cphys, Cout, stride, ones, ngroups, spw, ob_count, ib_count, tx0;
+  int N, H, W, Ho, Wo, Cin, Cphys, Cout, stride, ones, ngroups, spw, ob_count, ib_count, tap_lo;   // tap_lo: first tap of this pass
   int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
 };
 
@@ -950,7 +950,8 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   // barrier.  For 3x3 layers wave w instead owns taps 2w and 2w+1 outright and every 4th k-step (ks % 4 == w) of tap 8:
   // 9 tap-k-steps per 4 k-steps for every wave, still three accumulator sets per wave (tap 8 is flushed as four partials).
   const bool bal9 = ntaps == 9 && MAXT == 3 && sizeof(T) == 4;   // (bf16: measured slower, its k-loop is not MFMA-bound)
-  auto tap_of = [&](int t) { return split_k ? t : (bal9 ? (t < 2 ? 2 * wave + t : 8) : wave + 4 * t); };
+  // a.tap_lo: classes with more taps than 4 waves x MAXT accumulators run as several passes over tap ranges
+  auto tap_of = [&](int t) { return split_k ? t : (bal9 ? (t < 2 ? 2 * wave + t : 8) : a.tap_lo + wave + 4 * t); };
   int toff[MAXT];                                             // LDS offset of this wave's taps inside the halo tile
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
@@ -1306,7 +1307,7 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     a.G[g] = G[s]; a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
     if (kh[s] * kw[s] > maxtaps) maxtaps = kh[s] * kw[s];
   }
-  a.tx0 = 0;
+  a.tap_lo = 0;
   if (stride == 1) {
     // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels); one launch per kernel-size class so the
     //      per-wave accumulator count (MAXT) matches the class (3x3 -> 3, 5x5 -> 7, 7x7 -> 13)
@@ -1325,8 +1326,9 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     // feasibility of every class first (fall back to v1 as a whole otherwise)
     for (int g = 0; g < ngroups && ok; ++g) {
       const int taps = kh[g] * kw[g];
-      const int mt = taps < 4 ? taps : (taps + 3) / 4;
-      const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
+      const int passes = taps > 28 ? (taps + 27) / 28 : 1;
+      const int mt = passes > 1 ? 7 : (taps < 4 ? taps : (taps + 3) / 4);
+      const int OT = ((passes == 1 && mt > 7) || Cout <= 32) ? 1 : 2;
       const int OBP = (OT == 2 && esz == 2) ? 96 : 32 * OT;
       const size_t lds = (size_t)esz * (PTpx * OBP + (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1) * WG2_IB);
       if (lds > 64 * 1024 || mt > 13) ok = false;
@@ -1338,8 +1340,11 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
         for (int g2 = g; g2 < ngroups; ++g2)
           if (!done[g2] && kh[g2] == kh[g] && kw[g2] == kw[g]) { gm.groups[gm.ngr++] = g2; done[g2] = true; }
         const int taps = kh[g] * kw[g];
-        const int mt = taps < 4 ? taps : (taps + 3) / 4;
-        const int OT = (mt > 7 || Cout <= 32) ? 1 : 2;
+        // 13 accumulator sets per wave (7x7) do not fit the register file (the MAXT = 13 instantiation spills ~250 VGPRs):
+        // such classes run as ceil(taps / 28) passes of the 7-set kernel over tap ranges (the tiles are staged once per pass)
+        const int passes = taps > 28 ? (taps + 27) / 28 : 1;
+        const int mt = passes > 1 ? 7 : (taps < 4 ? taps : (taps + 3) / 4);
+        const int OT = ((passes == 1 && mt > 7) || Cout <= 32) ? 1 : 2;
         const int OB = 32 * OT, OBP = (OT == 2 && esz == 2) ? OB + 32 : OB;
         const int halo = (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1);
         const size_t lds = (size_t)esz * (PTpx * OBP + halo * WG2_IB);
@@ -1377,8 +1382,12 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
   if (mt <= 3) WG2_LAUNCH(TT, OTv, 3);                               \
   else if (mt <= 7) WG2_LAUNCH(TT, OTv, 7);                          \
   else WG2_LAUNCH(TT, OTv, 13);
-        if (dtype == HDMOE_F32) { if (OT == 2) { WG2_BY_MT(float, 2) } else { WG2_BY_MT(float, 1) } }
-        else { if (OT == 2) { WG2_BY_MT(bf16, 2) } else { WG2_BY_MT(bf16, 1) } }
+        for (int pass = 0; pass < passes; ++pass) {
+          a.tap_lo = 28 * pass;
+          if (dtype == HDMOE_F32) { if (OT == 2) { WG2_BY_MT(float, 2) } else { WG2_BY_MT(float, 1) } }
+          else { if (OT == 2) { WG2_BY_MT(bf16, 2) } else { WG2_BY_MT(bf16, 1) } }
+        }
+        a.tap_lo = 0;
       }
       return hdmoe_launch_status();
     }

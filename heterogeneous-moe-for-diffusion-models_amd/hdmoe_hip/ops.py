@@ -142,9 +142,10 @@ def _wgrad_name(tname, O, tap_classes):
     """Kernel instantiation(s) hdmoe_conv_wgrad picks (mirrors csrc/conv.hip: one launch per kernel-size class)."""
     names = []
     for taps in tap_classes:
-        mt = taps if taps < 4 else (taps + 3) // 4
-        ot = 1 if (mt > 7 or O <= 32) else 2
-        names.append(f"{ot}, {3 if mt <= 3 else (7 if mt <= 7 else 13)}")
+        passes = (taps + 27) // 28 if taps > 28 else 1
+        mt = 7 if passes > 1 else (taps if taps < 4 else (taps + 3) // 4)
+        ot = 1 if ((passes == 1 and mt > 7) or O <= 32) else 2
+        names.append(f"{ot}, {3 if mt <= 3 else (7 if mt <= 7 else 13)}" + (f" x{passes} passes" if passes > 1 else ""))
     if len(names) == 1:
         return f"conv_wgrad2_kernel<{tname}, {names[0]}, true>"
     return f"conv_wgrad2_kernel<{tname}, {{{' | '.join(names)}}}, true> ({len(names)} launches per call)"
