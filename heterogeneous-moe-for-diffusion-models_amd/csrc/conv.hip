@@ -1313,7 +1313,10 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     //      per-wave accumulator count (MAXT) matches the class (3x3 -> 3, 5x5 -> 7, 7x7 -> 13)
     Wg2Geom gm;
     const int PTpx = dtype == HDMOE_F32 ? Wg2PT<float>::N : Wg2PT<bf16>::N;
-    gm.TW = Wo < PTpx ? Wo : PTpx;
+    // near-square tiles keep the halo small (a 2 x 64 tile of a 7x7 layer needs 8 x 70 halo pixels, a 4 x 32 tile 10 x 38);
+    // single-row tensors (flattened token rows) take the whole tile width
+    const int tw_cap = Ho == 1 ? PTpx : 32;
+    gm.TW = Wo < tw_cap ? Wo : tw_cap;
     gm.TH = PTpx / gm.TW; if (gm.TH > Ho) gm.TH = Ho; if (gm.TH < 1) gm.TH = 1;
     gm.tw_shift = -1;
     for (int sft = 0; sft < 8; ++sft) if ((1 << sft) == gm.TW) gm.tw_shift = sft;
