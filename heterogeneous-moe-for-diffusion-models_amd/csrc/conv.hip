@@ -559,7 +559,9 @@ template <> struct Quad<bf16> { typedef bf16x4 type; };
 template <> struct Quad<float> { typedef f32x4 type; };
 
 template <typename T, int NT, bool LEPI, int NHR>
-__global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg) {
+__global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg_flags) {
+  const int tg = tg_flags & 0xFFFF;
+  const bool tile2d = (tg_flags >> 16) & 1;                  // 8 x 32 block tile of a wider image (TW == 32)
   constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16;
   constexpr int NB = 32 * NT, LNB = NT == 1 ? 5 : (NT == 2 ? 6 : 7);
   constexpr int NWR = 9;                                    // 16-B weight pieces per thread held in registers (halo: NHR, 7 or 9)
@@ -688,6 +690,13 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
   T* y = (T*)a.y + (long)n * HWo * a.Cstore;
   const T* res = a.res ? (const T*)a.res + (long)n * HWo * a.Cstore : nullptr;
   const int qlim = (TH > 1) ? npx : min(npx, a.Wo - tx0);
+  // image position of tile pixel q: a linear run (whole rows, or a slice of one row) unless the tile is an 8 x 32 block
+  auto pix_lin = [&](int q, bool& ok) -> long {
+    if (!tile2d) { const long lin = lin0 + q; ok = q < qlim && lin < HWo; return lin; }
+    const int ty = q >> 5, tx = q & 31;
+    ok = q < npx && ty0 + ty < a.Ho && tx0 + tx < a.Wo;
+    return lin0 + (long)ty * a.Wo + tx;
+  };
   if constexpr (LEPI) {
     // Through LDS: a quad store straight from the accumulator layout hands the memory system 32 separate 8/16-byte
     // pieces per instruction (one per pixel row).  Each wave instead parks its 64 x NB tile in its own LDS slab
@@ -702,8 +711,8 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
 #pragma unroll
     for (int m = 0; m < CV2_MT; ++m) {
       const int q = wave * (32 * CV2_MT) + m * 32 + r;
-      const long lin = lin0 + q;
-      const bool ok = q < qlim && lin < HWo;
+      bool ok;
+      const long lin = pix_lin(q, ok);
       const long pix = lin * a.Cstore + nbase + 4 * h;
 #pragma unroll
       for (int b = 0; b < NT; ++b)
@@ -726,8 +735,9 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
       for (int j = 0; j < 32 / PXI; ++j) {
         const int pl = j * PXI + prow;                       // pixel within the 32 of this m-fragment
         const int q2 = wave * (32 * CV2_MT) + m * 32 + pl;
-        const long lin2 = lin0 + q2;
-        if (q2 < qlim && lin2 < HWo && cch < a.Cstore) {
+        bool ok2;
+        const long lin2 = pix_lin(q2, ok2);
+        if (ok2 && cch < a.Cstore) {
           const uint4 v = *reinterpret_cast<const uint4*>(sE + pl * ROW + piece * VW);
           *reinterpret_cast<uint4*>(y + lin2 * a.Cstore + cch) = v;
         }
@@ -738,8 +748,9 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
 #pragma unroll
     for (int m = 0; m < CV2_MT; ++m) {
       const int q = wave * (32 * CV2_MT) + m * 32 + r;
-      const long lin = lin0 + q;
-      if (q < qlim && lin < HWo) {
+      bool ok;
+      const long lin = pix_lin(q, ok);
+      if (ok) {
         const long pix = lin * a.Cstore + nbase + 4 * h;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
@@ -1224,12 +1235,23 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
   if (stride == 1 && (long)Ho * Wo >= 64 && !getenv("HDMOE_CONV_V1")) {
     // ---- v2: LDS-staged 256-pixel tiles
     const int PT = 4 * CV2_MT * 32;
-    const int TW = Wo < PT ? Wo : PT;
-    int TH = PT / TW; if (TH > Ho) TH = Ho; if (TH < 1) TH = 1;
-    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, TW);
     int maxkh = 1, maxkw = 1;
     for (int g = 0; g < ngroups; ++g) { if (kh[g] > maxkh) maxkh = kh[g]; if (kw[g] > maxkw) maxkw = kw[g]; }
     const int esz = dtype == HDMOE_BF16 ? 2 : 4;
+    static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
+    const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
+    // Tile = whole image rows, or (v5 only, images wider than 32 with a real kernel window) 8 x 32 blocks: a 4 x 64 tile of a
+    // 7x7 layer needs a 10 x 70 halo, the 8 x 32 block 14 x 38.  tile2d != 0 tells the kernel the tile is not a linear pixel run.
+    const int NTq = Cstore <= 32 ? 1 : 2;
+    const bool vecq = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
+    // (only when the v5 launch below is certain: the older kernels assume linear tiles)
+    const bool tile2d = v5ok && vecq && Ho >= 8 && Wo > 32 && Wo % 32 == 0 && maxkh * maxkw > 1 && !getenv("HDMOE_CONV_V2") &&
+                        (8 + maxkh - 1) * (32 + maxkw - 1) * 4 <= 9 * 256 && maxkw * 32 * NTq <= 576 &&
+                        (long)maxkh * maxkw * Cout * Ipad < (1l << 26) && (long)H * W * Cphys < (1l << 30) &&
+                        (size_t)80 * ((8 + maxkh - 1) * (32 + maxkw - 1) + maxkw * 32 * NTq) <= 80 * 1024;
+    const int TW = tile2d ? 32 : (Wo < PT ? Wo : PT);
+    int TH = PT / TW; if (TH > Ho) TH = Ho; if (TH < 1) TH = 1;
+    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, TW);
     const int NT = Cstore <= 32 ? 1 : 2;
     const int halo_cap = (TH + maxkh - 1) * (TW + maxkw - 1);
     const size_t lds = (size_t)80 * (halo_cap + maxkw * 32 * NT);
@@ -1237,8 +1259,6 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     dim3 grid(tiles_y * tiles_x, N, cdiv(Cstore, 32 * NT));
     // v5 / v3 (register prefetch): rows of weights per stage <= 576 (9 chunks/thread); halo <= 448 px (7 chunks/thread), or for
     // v5 <= 576 px (9 chunks/thread: 7x7 experts, whose halo of a 256-pixel tile is 14 x 38 or 22 x 22 pixels)
-    static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
-    const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
     const int halo_max = v5ok ? 9 * 256 : 7 * 256;
     if (vec && halo_cap * 4 <= halo_max && maxkw * 32 * NT <= 576 && (long)maxkh * maxkw * Cout * Ipad < (1l << 26) &&
         (long)H * W * Cphys < (1l << 30) && !getenv("HDMOE_CONV_V2")) {
@@ -1259,11 +1279,12 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
         // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 32 px x (32 NT + pad) elements
         const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 32 * (32 * NT + 16 / esz) * esz <= lds3;
         const bool big_halo = halo_cap * 4 > 7 * 256;
+        const int tg5 = tg | (tile2d ? 1 << 16 : 0);             // bit 16: 8 x 32 block tiles (TW = 32 < Wo)
 #define CV5_LAUNCH(TT, NTv)                                                                                                                        \
-  do { if (lepi && !big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);   \
-       else if (!big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); \
-       else if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);       \
-       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg); } while (0)
+  do { if (lepi && !big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5);   \
+       else if (!big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5); \
+       else if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5);       \
+       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5); } while (0)
         if (dtype == HDMOE_F32) { if (NT == 1) CV5_LAUNCH(float, 1); else CV5_LAUNCH(float, 2); }
         else { if (NT == 1) CV5_LAUNCH(bf16, 1); else CV5_LAUNCH(bf16, 2); }
         return hdmoe_launch_status();

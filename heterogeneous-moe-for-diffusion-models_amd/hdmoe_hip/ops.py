@@ -111,12 +111,15 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
     esz = x.element_size()
     vec = cphys % (16 // esz) == 0
     tname = "float" if x.dtype == torch.float32 else "__bf16"
-    tw = min(Wo, 256)
-    th = max(1, min(256 // tw, Ho))
     nt = 1 if Cstore <= 32 else 2
+    v5ok = I == cphys and Cstore % 4 == 0
+    mk, mw = max(khs), max(kws)
+    tile2d = (v5ok and vec and Ho >= 8 and Wo > 32 and Wo % 32 == 0 and mk * mw > 1 and (8 + mk - 1) * (32 + mw - 1) * 4 <= 9 * 256
+              and mw * 32 * nt <= 576 and 80 * ((8 + mk - 1) * (32 + mw - 1) + mw * 32 * nt) <= 80 * 1024)
+    tw = 32 if tile2d else min(Wo, 256)
+    th = max(1, min(256 // tw, Ho))
     lds = 80 * ((th + max(khs) - 1) * (tw + max(kws) - 1) + max(kws) * 32 * nt)
     halo = (th + max(khs) - 1) * (tw + max(kws) - 1)
-    v5ok = I == cphys and Cstore % 4 == 0
     if Ho * Wo >= 64 and vec and halo * 4 <= (9 if v5ok else 7) * 256 and max(kws) * 32 * nt <= 576:
         tg = min(576 // (max(kws) * 32 * nt), max(khs))
         while tg > 1 and 80 * (halo + tg * max(kws) * 32 * nt) > 64 * 1024:
