@@ -81,10 +81,11 @@ def pmc_traffic(kernel_name):
     if not files:
         return None
     tbl = json.load(open(files[-1]))
-    m = re.match(r"(\w+)<(\w+), (\d+)", kernel_name)
     keys = [kernel_name]
-    if m:                                                   # rocprof prints bf16 instantiations mangled
-        keys.append(f"{m.group(1)}IDF16bLi{m.group(3)}")
+    m = re.match(r"(\w+)<__bf16, (.*)>", kernel_name)
+    if m:                                                   # rocprof prints bf16 instantiations mangled: IDF16b + Li<n>E / Lb<0|1>E
+        args = "".join(("Lb1E" if a == "true" else "Lb0E" if a == "false" else f"Li{a}E") for a in m.group(2).split(", ") if a.strip("-").isdigit() or a in ("true", "false"))
+        keys = [f"{m.group(1)}IDF16b{args}"]
     for k, v in tbl.items():
         if any(key in k for key in keys):
             return round(v["hbm_read_bytes_per_launch_corrected"] + v["hbm_write_bytes_per_launch"])
