@@ -559,7 +559,7 @@ template <> struct Quad<bf16> { typedef bf16x4 type; };
 template <> struct Quad<float> { typedef f32x4 type; };
 
 template <typename T, int NT, bool LEPI, int NHR>
-__global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg_flags) {
+__global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int TW, int tiles_x, int halo_cap, int tg_flags, int ntiles) {
   const int tg = tg_flags & 0xFFFF;
   const bool tile2d = (tg_flags >> 16) & 1;                  // 8 x 32 block tile of a wider image (TW == 32)
   constexpr int ESZ = sizeof(T), VW = 16 / ESZ, KC = 64 / ESZ, PSE = KC + VW, KS = KC / 16;
@@ -571,11 +571,17 @@ __global__ __launch_bounds__(256) void conv_fwd5_kernel(ConvArgs a, int TH, int 
   T* sB = sA + (long)halo_cap * PSE;                         // [tg*kw][NB][PSE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the (image, tile) pairs are
+  // dealt to XCDs by pair % 8 and the channel blocks of one pair run back to back on the SAME XCD (ids L and L + 8): the second
+  // block finds the input tile the first one fetched in that L2 instead of reading it from HBM again.
+  const int nblk = (tg_flags >> 17) & 0x3FFF;
+  const int slot = blockIdx.x >> 3, pair = (slot / nblk) * 8 + (blockIdx.x & 7);
+  const int n = pair / ntiles, tile = pair - n * ntiles;
+  if (n >= a.N) return;
   const int g = find_group(a.seg, a.ngroups, n);
   if (g < 0) return;
-  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-  const int nbase = blockIdx.z * NB;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+  const int nbase = (slot % nblk) * NB;
   const int kh = a.kh[g], kw = a.kw[g], pt = a.pt[g], pl = a.pl[g];
   const int HWp = TW + kw - 1, HHp = TH + kh - 1;
   const int npx = TH * TW;
@@ -1279,12 +1285,16 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
         // LDS-transposed epilogue needs whole 16-B pieces per pixel and a slab of 4 waves x 32 px x (32 NT + pad) elements
         const bool lepi = Cstore % (16 / esz) == 0 && (size_t)4 * 32 * (32 * NT + 16 / esz) * esz <= lds3;
         const bool big_halo = halo_cap * 4 > 7 * 256;
-        const int tg5 = tg | (tile2d ? 1 << 16 : 0);             // bit 16: 8 x 32 block tiles (TW = 32 < Wo)
+        const int nblk5 = (int)cdiv(Cstore, 32 * NT), ntiles5 = tiles_y * tiles_x;
+        const int tg5 = tg | (tile2d ? 1 << 16 : 0) | (nblk5 << 17);     // bit 16: 8 x 32 block tiles; bits 17-30: channel blocks
+        if (nblk5 > 0x3FFF) return HDMOE_EINVAL;
+        const long npairs = (long)N * ntiles5;
+        const dim3 grid5((unsigned)(8 * ((npairs + 7) / 8) * nblk5));
 #define CV5_LAUNCH(TT, NTv)                                                                                                                        \
-  do { if (lepi && !big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5);   \
-       else if (!big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 7>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5); \
-       else if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5);       \
-       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 9>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5); } while (0)
+  do { if (lepi && !big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 7>), grid5, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5, ntiles5);   \
+       else if (!big_halo) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 7>), grid5, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5, ntiles5); \
+       else if (lepi) hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, true, 9>), grid5, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5, ntiles5);       \
+       else hipLaunchKernelGGL((conv_fwd5_kernel<TT, NTv, false, 9>), grid5, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg5, ntiles5); } while (0)
         if (dtype == HDMOE_F32) { if (NT == 1) CV5_LAUNCH(float, 1); else CV5_LAUNCH(float, 2); }
         else { if (NT == 1) CV5_LAUNCH(bf16, 1); else CV5_LAUNCH(bf16, 2); }
         return hdmoe_launch_status();
