@@ -208,10 +208,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # HDMOE_BENCH_BACKEND=gloo rehearses the multi-process control flow on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("HDMOE_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     import hdmoe_hip
@@ -245,6 +251,10 @@ def main():
         l = fwd_bwd()
         buckets.finish()                                    # RCCL all-reduce of the flat gradient buckets when world > 1
         return {"loss": l}
+
+    def local_step():                                       # one eager step without the gradient exchange (roofline leg, rank 0 only)
+        ops.advance_seed(device)
+        return {"loss": fwd_bwd()}
 
     step = eager_step
     if not args.no_graph:
@@ -296,7 +306,7 @@ def main():
     cpu = None
     if rank == 0:
         if not args.no_roofline:
-            roof, table = roofline_leg(eager_step, 3)       # per-launch events need eager launches
+            roof, table = roofline_leg(local_step, 3)       # per-launch events need eager launches; rank-local (no collective)
             if args.dump_kernels:
                 with open(args.dump_kernels, "w") as f:
                     json.dump(table, f, indent=1)
