@@ -423,6 +423,66 @@ __global__ __launch_bounds__(512) void groupnorm_stats_vec_kernel(float* mean, f
     }
   }
 }
+// Small batches: one 512-thread block per sample leaves most of the chip idle (32 samples = 32 blocks).  Split each sample's
+// rows over `parts` blocks: every block reduces its row range to per-group (mean, M2) with the same two-pass scheme, and a
+// second kernel merges the partials in a fixed order (Chan et al.), so the result stays deterministic.
+template <typename T>
+__global__ __launch_bounds__(512) void groupnorm_part_stats_vec_kernel(float* ws, const T* x, long S, int C, int G, int parts) {
+  constexpr int W = VT<T>::W;
+  __shared__ float part[512];
+  __shared__ float red[64];
+  const int n = blockIdx.x, pi = blockIdx.y, Cg = C / G, cv = C / W;
+  const long rpp = (S + parts - 1) / parts;
+  const long r0 = min((long)pi * rpp, S), r1 = min(r0 + rpp, S);
+  const T* xs = x + ((long)n * S + r0) * C;
+  const long nv = (r1 - r0) * cv;
+  const int mych = (threadIdx.x % cv) * W;
+  const int g = mych / Cg;
+  const float cnt = (float)((r1 - r0) * Cg);
+  float acc = 0.f;
+  for (long v = threadIdx.x; v < nv; v += blockDim.x) {
+    float f[W];
+    vload<T>(f, xs + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc += f[j];
+  }
+  vec_group_reduce(acc, cv, W, Cg, G, part, red);
+  const float m = cnt > 0.f ? red[g] / cnt : 0.f;
+  acc = 0.f;
+  for (long v = threadIdx.x; v < nv; v += blockDim.x) {
+    float f[W];
+    vload<T>(f, xs + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) { const float d = f[j] - m; acc += d * d; }
+  }
+  const float mkeep = m;
+  vec_group_reduce(acc, cv, W, Cg, G, part, red);
+  if ((int)threadIdx.x < cv && (mych % Cg) == 0) {
+    float* o = ws + (((long)n * parts + pi) * G + g) * 2;
+    o[0] = mkeep; o[1] = red[g];
+  }
+}
+__global__ void groupnorm_merge_kernel(float* mean, float* rstd, const float* ws, long S, int C, int G, int parts, float eps, long NG) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (sample, group)
+  if (i >= NG) return;
+  const long n = i / G; const int g = (int)(i - n * G);
+  const int Cg = C / G;
+  const long rpp = (S + parts - 1) / parts;
+  float cnt = 0.f, m = 0.f, M2 = 0.f;
+  for (int pi = 0; pi < parts; ++pi) {
+    const long r0 = min((long)pi * rpp, S), r1 = min(r0 + rpp, S);
+    const float c2 = (float)((r1 - r0) * Cg);
+    if (c2 <= 0.f) continue;
+    const float* o = ws + ((n * parts + pi) * G + g) * 2;
+    const float d = o[0] - m, tot = cnt + c2;
+    m += d * (c2 / tot);
+    M2 += o[1] + d * d * (cnt * c2 / tot);
+    cnt = tot;
+  }
+  mean[i] = m;
+  rstd[i] = rsqrtf(M2 / cnt + eps);
+}
+
 template <typename T>
 __global__ void groupnorm_apply_vec_kernel(T* y, const T* x, const float* gamma, const float* beta, const float* mean,
                                            const float* rstd, long S, int C, int G, int act, long nvec) {
@@ -442,12 +502,15 @@ __global__ void groupnorm_apply_vec_kernel(T* y, const T* x, const float* gamma,
 template <typename T>
 __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const T* dy,
                                                                      const T* x, const float* gamma, const float* beta, const float* mean,
-                                                                     const float* rstd, long S, int C, int G, int act) {
+                                                                     const float* rstd, long S, int C, int G, int act, int parts) {
   constexpr int W = VT<T>::W;
   __shared__ float part[512], part2[512];
   const int n = blockIdx.x, Cg = C / G, cv = C / W;
-  const long base = (long)n * S * C;
-  const long nv = S * cv;
+  // parts > 1 (small batches): blockIdx.y owns a row range and adds its sums into the pre-zeroed s1 / s2
+  const long rpp = (S + parts - 1) / parts;
+  const long r0 = min((long)blockIdx.y * rpp, S), r1 = min(r0 + rpp, S);
+  const long base = ((long)n * S + r0) * C;
+  const long nv = (r1 - r0) * cv;
   const int mych = (threadIdx.x % cv) * W;
   const int g = mych / Cg;
   const float m = mean[(long)n * G + g], rs = rstd[(long)n * G + g];
@@ -469,9 +532,9 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
   }
   __shared__ float red[64];
   vec_group_reduce(a1, cv, W, Cg, G, part, red);
-  if ((int)threadIdx.x < G) s1[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  if ((int)threadIdx.x < G) { if (parts > 1) atomicAdd(&s1[(long)n * G + threadIdx.x], red[threadIdx.x]); else s1[(long)n * G + threadIdx.x] = red[threadIdx.x]; }
   vec_group_reduce(a2, cv, W, Cg, G, part, red);
-  if ((int)threadIdx.x < G) s2[(long)n * G + threadIdx.x] = red[threadIdx.x];
+  if ((int)threadIdx.x < G) { if (parts > 1) atomicAdd(&s2[(long)n * G + threadIdx.x], red[threadIdx.x]); else s2[(long)n * G + threadIdx.x] = red[threadIdx.x]; }
   // per-channel partials: strided tree over the threads that share a channel chunk, then one global atomic per channel
 #pragma unroll
   for (int j = 0; j < W; ++j) {
@@ -575,13 +638,18 @@ static int gn_check(int N, int C, int G) {
   if (N < 1 || G < 1 || G > 64 || (G & (G - 1)) || C % G || C > 4096) return HDMOE_EINVAL;   // G must divide 512 (thread<->group map)
   return HDMOE_OK;
 }
-int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int N,
-                        long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
-  if (gn_check(N, C, G)) return HDMOE_EINVAL;
+static int groupnorm_fwd_impl(void* y, float* mean, float* rstd, float* ws, int parts, const void* x, const float* gamma, const float* beta,
+                              int N, long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
+  if (gn_check(N, C, G) || parts < 1 || parts > 64) return HDMOE_EINVAL;
   const long n = (long)N * S * C;
   DT_SWITCH(dtype, if (gn_vec_ok<T>(C, G, y, x, nullptr)) {
     const long nvec = n / VT<T>::W;
-    hipLaunchKernelGGL(groupnorm_stats_vec_kernel<T>, dim3(N), dim3(512), 0, stream, mean, rstd, (const T*)x, S, C, G, eps);
+    if (ws && parts > 1) {
+      hipLaunchKernelGGL(groupnorm_part_stats_vec_kernel<T>, dim3(N, parts), dim3(512), 0, stream, ws, (const T*)x, S, C, G, parts);
+      hipLaunchKernelGGL(groupnorm_merge_kernel, dim3(cdiv((long)N * G, 64)), dim3(64), 0, stream, mean, rstd, ws, S, C, G, parts, eps, (long)N * G);
+    } else {
+      hipLaunchKernelGGL(groupnorm_stats_vec_kernel<T>, dim3(N), dim3(512), 0, stream, mean, rstd, (const T*)x, S, C, G, eps);
+    }
     hipLaunchKernelGGL(groupnorm_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)y, (const T*)x, gamma, beta, mean, rstd, S, C, G, act, nvec);
     return hdmoe_launch_status();
   })
@@ -591,17 +659,25 @@ int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const 
   })
   return hdmoe_launch_status();
 }
+int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int N,
+                        long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
+  return groupnorm_fwd_impl(y, mean, rstd, nullptr, 1, x, gamma, beta, N, S, C, G, act, eps, dtype, stream);
+}
+int hdmoe_groupnorm_fwd_split(void* y, float* mean, float* rstd, float* ws, int parts, const void* x, const float* gamma,
+                              const float* beta, int N, long S, int C, int G, int act, float eps, int dtype, hipStream_t stream) {
+  return groupnorm_fwd_impl(y, mean, rstd, ws, parts, x, gamma, beta, N, S, C, G, act, eps, dtype, stream);
+}
 // ws: 2*N*G floats of scratch; dgamma/dbeta accumulate (caller zeroes)
-int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x, const float* gamma,
-                        const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
-                        int dtype, hipStream_t stream) {
-  if (gn_check(N, C, G)) return HDMOE_EINVAL;
+static int groupnorm_bwd_impl(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
+                              int dtype, hipStream_t stream) {
+  if (gn_check(N, C, G) || parts < 1 || parts > 64) return HDMOE_EINVAL;
   const long n = (long)N * S * C;
   float* s1 = ws; float* s2 = ws + (long)N * G;
   DT_SWITCH(dtype, if (gn_vec_ok<T>(C, G, dx, dy, x)) {
     const long nvec = n / VT<T>::W;
-    hipLaunchKernelGGL(groupnorm_bwd_stats_vec_kernel<T>, dim3(N), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const T*)dy, (const T*)x,
-                       gamma, beta, mean, rstd, S, C, G, act);
+    hipLaunchKernelGGL(groupnorm_bwd_stats_vec_kernel<T>, dim3(N, parts), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const T*)dy, (const T*)x,
+                       gamma, beta, mean, rstd, S, C, G, act, parts);
     hipLaunchKernelGGL(groupnorm_bwd_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
                        gamma, beta, mean, rstd, s1, s2, S, C, G, act, nvec);
     return hdmoe_launch_status();
@@ -613,6 +689,17 @@ int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const 
                        gamma, beta, mean, rstd, s1, s2, S, C, G, act, n);
   })
   return hdmoe_launch_status();
+}
+int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
+                        int dtype, hipStream_t stream) {
+  return groupnorm_bwd_impl(dx, dgamma, dbeta, ws, 1, dy, x, gamma, beta, mean, rstd, N, S, C, G, act, dtype, stream);
+}
+/* parts > 1: ws (2*N*G floats) must be zeroed by the caller; the row-range blocks add into it */
+int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
+                              int G, int act, int dtype, hipStream_t stream) {
+  return groupnorm_bwd_impl(dx, dgamma, dbeta, ws, parts, dy, x, gamma, beta, mean, rstd, N, S, C, G, act, dtype, stream);
 }
 int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
                         int C, float eps, int dtype, hipStream_t stream) {

@@ -1028,7 +1028,12 @@ class _GroupNormFn(torch.autograd.Function):
         mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         y = torch.empty_like(x)
-        call("hdmoe_groupnorm_fwd", y, mean, rstd, x, gamma, beta, N, S, C, G, act, eps, _dt(x))
+        parts = _gn_parts(N, S)
+        if parts > 1:
+            ws = torch.empty(2 * N * parts * G, dtype=torch.float32, device=x.device)
+            call("hdmoe_groupnorm_fwd_split", y, mean, rstd, ws, parts, x, gamma, beta, N, S, C, G, act, eps, _dt(x))
+        else:
+            call("hdmoe_groupnorm_fwd", y, mean, rstd, x, gamma, beta, N, S, C, G, act, eps, _dt(x))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.meta = (N, S, C, G, act)
         return y
@@ -1041,9 +1046,21 @@ class _GroupNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.zeros_like(gamma)
         dbeta = torch.zeros_like(beta)
-        ws = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
-        call("hdmoe_groupnorm_bwd", dx, dgamma, dbeta, ws, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
+        parts = _gn_parts(N, S)
+        if parts > 1:
+            ws = torch.zeros(2 * N * G, dtype=torch.float32, device=x.device)
+            call("hdmoe_groupnorm_bwd_split", dx, dgamma, dbeta, ws, parts, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
+        else:
+            ws = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
+            call("hdmoe_groupnorm_bwd", dx, dgamma, dbeta, ws, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
         return dx, dgamma, dbeta, None, None, None
+
+
+def _gn_parts(N: int, S: int) -> int:
+    """Row-range workgroups per sample for the GroupNorm statistics: one per sample fills the chip only from ~128 samples."""
+    if N >= 128 or S < 256:
+        return 1
+    return max(1, min(64, 256 // N, S // 128))
 
 
 ACT_NONE, ACT_RELU, ACT_MP_SILU = 0, 1, 2

@@ -134,6 +134,13 @@ int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const 
 int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x,
                         const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
                         int G, int act, int dtype, HS stream);                                                   /* ws: 2*N*G floats */
+/* small batches: each sample's rows are split over `parts` (<= 64) workgroups.  fwd ws: 2*N*parts*G floats (partial mean / M2,
+ * merged in a fixed order); bwd ws: 2*N*G floats that the CALLER ZEROES (row-range blocks add into them). */
+int hdmoe_groupnorm_fwd_split(void* y, float* mean, float* rstd, float* ws, int parts, const void* x, const float* gamma,
+                              const float* beta, int N, long S, int C, int G, int act, float eps, int dtype, HS stream);
+int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
+                              int G, int act, int dtype, HS stream);
 int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
                         int C, float eps, int dtype, HS stream);
 int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, const void* x, const float* gamma,
