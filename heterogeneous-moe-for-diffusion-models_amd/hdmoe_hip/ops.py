@@ -1046,7 +1046,7 @@ class _GroupNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.zeros_like(gamma)
         dbeta = torch.zeros_like(beta)
-        parts = _gn_parts(N, S)
+        parts = _gn_parts(N, S, forward=False)
         if parts > 1:
             ws = torch.zeros(2 * N * G, dtype=torch.float32, device=x.device)
             call("hdmoe_groupnorm_bwd_split", dx, dgamma, dbeta, ws, parts, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
@@ -1056,8 +1056,12 @@ class _GroupNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
-def _gn_parts(N: int, S: int) -> int:
-    """Row-range workgroups per sample for the GroupNorm statistics: one per sample fills the chip only from ~128 samples."""
+def _gn_parts(N: int, S: int, forward: bool = True) -> int:
+    """Row-range workgroups per sample for the GroupNorm statistics.  Forward: a function of S only -- the summation order, and
+    with it every bit of the output, must not depend on how many samples share the batch.  Backward (which sums with float
+    atomics anyway): only when one block per sample would leave the chip idle."""
+    if forward:
+        return max(1, min(4, S // 256))
     if N >= 128 or S < 256:
         return 1
     return max(1, min(64, 256 // N, S // 128))
