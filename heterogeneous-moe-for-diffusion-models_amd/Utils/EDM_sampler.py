@@ -69,8 +69,12 @@ class EDM_Sampler:
             with torch.cuda.graph(self._graph):
                 self._sout = self.denoise(self._sx, self._ssig, self._stext, transition_mean, softness, self._sunc)
             self._gkey = key
+        # every replay input is refreshed: a later sample() with another prompt of the same shape must not see the captured one
         self._sx.copy_(x)
         self._ssig.fill_(float(t))
+        self._stext.copy_(text_emb)
+        if self._sunc is not None:
+            self._sunc.copy_(uncond_text_emb)
         self._graph.replay()
         return self._sout.clone()
 

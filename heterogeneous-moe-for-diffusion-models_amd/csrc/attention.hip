@@ -542,6 +542,56 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
   return hdmoe_launch_status();
 }
 
+// ------------------------------------------------------------------ rel_pos_bias resize (S > S0)
+// Reference model_internals.py:388-397: F.interpolate(bias[None], size=(S,S), mode='bicubic', align_corners=False).
+// Cubic convolution, A = -0.75, source coordinate (dst + 0.5) * S0/S - 0.5 (not clamped), taps clamped to the table.
+struct CubicTaps { int i[4]; float c[4]; };
+DEVI CubicTaps cubic_taps(int dst, int S0, float scale) {
+  const float A = -0.75f;
+  const float real = scale * (dst + 0.5f) - 0.5f;
+  const float fl = floorf(real);
+  const float t = real - fl;
+  const int i0 = (int)fl;
+  CubicTaps r;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  r.c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  r.c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  r.c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  r.c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.i[k] = min(max(i0 - 1 + k, 0), S0 - 1);
+  return r;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bicubic_kernel(float* dst, const float* src, int H, int S0, int S) {
+  // forward: dst = out [H][S][S], src = table [H][S0][S0];  backward: dst = dtable (pre-zeroed, atomics), src = dout
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)H * S * S) return;
+  const int x = (int)(e % S), y = (int)((e / S) % S), h = (int)(e / ((long)S * S));
+  const float scale = (float)S0 / (float)S;
+  const CubicTaps ty = cubic_taps(y, S0, scale), tx = cubic_taps(x, S0, scale);
+  if (!BWD) {
+    const float* t = src + (long)h * S0 * S0;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row += tx.c[b] * t[(long)ty.i[a] * S0 + tx.i[b]];
+      acc += ty.c[a] * row;
+    }
+    dst[e] = acc;
+  } else {
+    float* t = dst + (long)h * S0 * S0;
+    const float g = src[e];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) atomicAdd(&t[(long)ty.i[a] * S0 + tx.i[b]], g * ty.c[a] * tx.c[b]);
+  }
+}
+
 }  // namespace
 
 #define D_SWITCH(D, CALL)                       \
@@ -573,6 +623,18 @@ int hdmoe_attn_bwd(void* dq, void* dk, void* dv, float* dbias, float* delta, con
   if (dtype == HDMOE_F32) { D_SWITCH(D, return (attn_bwd_launch<float, DD>(dq, dk, dv, dbias, delta, dout, out, q, k, v, lse, bias, B, Sq, Skv, H, Sb, stream))) }
   if (dtype == HDMOE_BF16) { D_SWITCH(D, return (attn_bwd_launch<bf16, DD>(dq, dk, dv, dbias, delta, dout, out, q, k, v, lse, bias, B, Sq, Skv, H, Sb, stream))) }
   return HDMOE_EDTYPE;
+}
+
+// out [H][S][S] <- table [H][S0][S0] (fwd);  dtable [H][S0][S0] (caller zeroes) += resize^T(dout [H][S][S]) (bwd)
+int hdmoe_bicubic_fwd(float* out, const float* table, int H, int S0, int S, hipStream_t stream) {
+  if (!out || !table || H < 1 || S0 < 1 || S < 1) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(bicubic_kernel<false>, dim3(cdiv((long)H * S * S, 256)), dim3(256), 0, stream, out, table, H, S0, S);
+  return hdmoe_launch_status();
+}
+int hdmoe_bicubic_bwd(float* dtable, const float* dout, int H, int S0, int S, hipStream_t stream) {
+  if (!dtable || !dout || H < 1 || S0 < 1 || S < 1) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(bicubic_kernel<true>, dim3(cdiv((long)H * S * S, 256)), dim3(256), 0, stream, dtable, dout, H, S0, S);
+  return hdmoe_launch_status();
 }
 
 }  // extern "C"

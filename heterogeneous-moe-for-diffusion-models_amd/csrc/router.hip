@@ -33,8 +33,8 @@ __global__ void router_head_fwd_kernel(float* sparse, float* probs, float* xout,
       mx = fmaxf(mx, v);
     }
     float sum = 0.f;
-    for (int e = 0; e < E; ++e) sum += __expf(xo[e] - mx);
-    for (int e = 0; e < E; ++e) { probs[b * E + e] = __expf(xo[e] - mx) / sum; sparse[b * E + e] = 0.f; }
+    for (int e = 0; e < E; ++e) sum += expf(xo[e] - mx);
+    for (int e = 0; e < E; ++e) { probs[b * E + e] = expf(xo[e] - mx) / sum; sparse[b * E + e] = 0.f; }
     // top-k by repeated argmax; ties -> lowest index (torch.topk's tie order is implementation-defined)
     unsigned long long taken = 0ull;
     float top = 0.f;
@@ -49,8 +49,8 @@ __global__ void router_head_fwd_kernel(float* sparse, float* probs, float* xout,
       if (j == 0) top = bv;
     }
     float ws = 0.f;
-    for (int j = 0; j < k; ++j) ws += __expf(xo[idx[b * k + j]] - top);
-    for (int j = 0; j < k; ++j) sparse[b * E + idx[b * k + j]] = __expf(xo[idx[b * k + j]] - top) / ws;
+    for (int j = 0; j < k; ++j) ws += expf(xo[idx[b * k + j]] - top);
+    for (int j = 0; j < k; ++j) sparse[b * E + idx[b * k + j]] = expf(xo[idx[b * k + j]] - top) / ws;
   }
 }
 
@@ -162,9 +162,10 @@ template <typename T>
 __global__ void combine_rows_bwd_kernel(T* dys, float* dsparse, const T* dout, const T* ys, const int* perm, const int* row_expert,
                                         const float* row_w, int E, long L, int chunk) {
   __shared__ float sm[16];
-  const int r = blockIdx.y;
+  const long nck = (L + chunk - 1) / chunk;
+  const long r = blockIdx.x / nck;                              // 1-D grid: (row, chunk) pairs, no 65535-row limit
   const int b = perm[r];
-  const long p0 = (long)blockIdx.x * chunk;
+  const long p0 = (long)(blockIdx.x - r * nck) * chunk;
   const long p1 = (p0 + chunk < L) ? p0 + chunk : L;
   const float w = b >= 0 ? (row_w ? row_w[r] : 1.f) : 0.f;
   float acc = 0.f;
@@ -224,14 +225,15 @@ int hdmoe_combine_rows_fwd(void* out, const void* ys, const int* inv, const floa
 }
 int hdmoe_combine_rows_bwd(void* dys, float* dsparse, const void* dout, const void* ys, const int* perm, const int* row_expert,
                            const float* row_w, long R, int E, long L, int dtype, hipStream_t stream) {
-  if (R > 65535) return HDMOE_EINVAL;
   const int chunk = 8192;
-  dim3 grid(cdiv(L, chunk), (unsigned)R);
+  if (R < 0 || L < 1 || R * (long)cdiv(L, chunk) >= (1l << 31)) return HDMOE_EINVAL;
+  if (R == 0) return HDMOE_OK;
+  dim3 grid((unsigned)(R * (long)cdiv(L, chunk)));
   if (dtype == HDMOE_F32) hipLaunchKernelGGL(combine_rows_bwd_kernel<float>, grid, dim3(TPB), 0, stream, (float*)dys, dsparse, (const float*)dout, (const float*)ys, perm, row_expert, row_w, E, L, chunk);
   else if (dtype == HDMOE_BF16) hipLaunchKernelGGL(combine_rows_bwd_kernel<bf16>, grid, dim3(TPB), 0, stream, (bf16*)dys, dsparse, (const bf16*)dout, (const bf16*)ys, perm, row_expert, row_w, E, L, chunk);
   else return HDMOE_EDTYPE;
   return hdmoe_launch_status();
 }
-int hdmoe_version(void) { return 100; }
+int hdmoe_version(void) { return 200; }
 
 }  // extern "C"

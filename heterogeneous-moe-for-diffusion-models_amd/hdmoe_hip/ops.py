@@ -1144,6 +1144,30 @@ class _AttnFn(torch.autograd.Function):
         return dq, dk, dv, dbias, None
 
 
+class _BicubicFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, S):
+        table = _f32(table)
+        H, S0, _ = table.shape
+        out = torch.empty((H, S, S), dtype=torch.float32, device=table.device)
+        call("hdmoe_bicubic_fwd", out, table, H, S0, S)
+        ctx.dims = (H, S0, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, S0, S = ctx.dims
+        dt = torch.zeros((H, S0, S0), dtype=torch.float32, device=g.device)
+        call("hdmoe_bicubic_bwd", dt, _f32(g), H, S0, S)
+        return dt, None
+
+
+def bicubic_resize(table: Tensor, S: int) -> Tensor:
+    """(H,S0,S0) -> (H,S,S): F.interpolate(mode='bicubic', align_corners=False) of the rel_pos_bias table
+    (reference model_internals.py:388-397)."""
+    return _BicubicFn.apply(table, int(S))
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor], num_heads: int) -> Tensor:
     """softmax(q k^T / sqrt(D) + bias) v per head; (B,S,E) tensors, head h = channels [h*D,(h+1)*D)."""
     return _AttnFn.apply(q, k, v, bias, int(num_heads))

@@ -180,10 +180,9 @@ class MP_Attention(nn.Module):
                 v = ops.seq_bcast_add(v, self.v_time._fwd(te, gain_t))
         bias = None
         if not self.is_cross:
-            if seq_len > self.rel_pos_bias.shape[1]:
-                raise NotImplementedError("MP_Attention: bicubic resize of rel_pos_bias (seq_len > trained seq_ln) is not "
-                                          "implemented in the HIP path")
             bias = self.rel_pos_bias                      # the kernel reads the [:S, :S] corner in place
+            if seq_len > bias.shape[1]:                   # longer than trained: bicubic resize of the table (:388-397)
+                bias = ops.bicubic_resize(bias, seq_len)
         o = ops.attention(q, k, v, bias, self.num_heads)
         t = self.attn_balance
         n = math.sqrt((1.0 - t) ** 2 + t ** 2)

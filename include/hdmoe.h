@@ -153,6 +153,11 @@ int hdmoe_attn_bwd(void* dq, void* dk, void* dv, float* dbias, float* delta, con
                    const void* q, const void* k, const void* v, const float* lse, const float* bias, int B, int Sq,
                    int Skv, int H, int D, int Sb, int dtype, HS stream);
 
+/* rel_pos_bias resize for S > S0 (model_internals.py:388-397: F.interpolate(..., mode='bicubic', align_corners=False)).
+ * fwd: out [H][S][S] <- table [H][S0][S0];  bwd: dtable (caller zeroes) += transpose of the same linear map applied to dout. */
+int hdmoe_bicubic_fwd(float* out, const float* table, int H, int S0, int S, HS stream);
+int hdmoe_bicubic_bwd(float* dtable, const float* dout, int H, int S0, int S, HS stream);
+
 /* ---- K1/K2: router head + dispatch  (model_components.py:155-168, model_config1.py:11-39) ---------------------- */
 int hdmoe_router_head_fwd(float* sparse, float* probs, float* xout, int* idx, const float* logits, const float* noise,
                           const float* mask, long B, int E, int k, HS stream);

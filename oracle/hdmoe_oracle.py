@@ -477,3 +477,25 @@ def mask_generator(sigma: Tensor, attrs: Sequence[float], p_mean: float, p_std: 
     mask = (dist <= bandwidth).float()
     mask.scatter_(1, torch.topk(-dist, k=min_active, dim=-1).indices, 1.0)
     return mask
+
+
+def edm_sampler(denoise, noise: Tensor, num_steps: int, sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7.0) -> Tensor:
+    """Deterministic (S_churn = 0) Heun sampler, Utils/EDM_sampler.py:73-109.  ``denoise(x, t)`` -> D(x; t) with ``t`` a
+    0-dim tensor; classifier-free guidance (:57-70) is the caller's ``ref.lerp(D, g)`` inside ``denoise``."""
+    i = torch.arange(num_steps, dtype=noise.dtype)
+    t = (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    t = torch.cat([t, torch.zeros_like(t[:1])])
+    x = noise * t[0]
+    for k in range(num_steps):
+        d = (x - denoise(x, t[k])) / t[k]
+        xn = x + (t[k + 1] - t[k]) * d
+        if k < num_steps - 1:
+            dp = (xn - denoise(xn, t[k + 1])) / t[k + 1]
+            xn = x + (t[k + 1] - t[k]) * (0.5 * d + 0.5 * dp)
+        x = xn
+    return x
+
+
+def cfg_lerp(d_model: Tensor, d_guide: Tensor, guidance: float) -> Tensor:
+    """Utils/EDM_sampler.py:57-70: ref_D_x.lerp(D_x, guidance)."""
+    return d_guide.lerp(d_model, guidance) if guidance != 1.0 else d_model

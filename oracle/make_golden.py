@@ -24,6 +24,7 @@ import models.model_components as mc         # noqa: E402  (reference)
 import models.model_config1 as c1            # noqa: E402  (reference)
 import models.model_config2 as c2            # noqa: E402  (reference)
 import utils as ru                           # noqa: E402  (reference Utils/utils.py)
+import EDM_sampler as rs                     # noqa: E402  (reference Utils/EDM_sampler.py)
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
@@ -325,6 +326,43 @@ def wide_model(cfg_id, B, seed):
           f"V {float(margin['vit_raw'].min()):.4f} |denoised| {float(out['denoised'].abs().max()):.3f}")
 
 
+class SamplerMock(torch.nn.Module):
+    """Deterministic stand-in for the denoiser (same role as the reference's tests/test_utilities/test_sampler.py:6-23 mock),
+    but sensitive to every argument the sampler forwards: sigma (0-dim), the text embedding and transition_point/softness."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.num_experts = 4
+        self.a, self.b = a, b
+
+    def forward(self, x, sigma, text_emb, Unet_router_mask, Vit_router_mask, zeta, transition_point, softness,
+                return_log_var=False):
+        assert sigma.ndim == 0 and Unet_router_mask.shape == (x.shape[0], self.num_experts) and zeta == 0
+        s = sigma.to(x.dtype)
+        t = text_emb.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+        return {"denoised": x * (self.a / (1.0 + s * s)) + self.b * t * torch.tanh(s) + 0.01 * transition_point * softness}
+
+
+def sampler_fixture():
+    """Row N1: trajectories of the REFERENCE EDM_Sampler (Utils/EDM_sampler.py:73-109, CFG :57-70) over SamplerMock."""
+    gen = torch.Generator().manual_seed(41)
+    noise = torch.randn(3, 4, 8, 8, generator=gen)
+    text = torch.randn(3, 5, 16, generator=gen)
+    text2 = torch.randn(3, 5, 16, generator=gen)
+    unc = torch.randn(3, 5, 16, generator=gen)
+    cases = []
+    for guide, N, use_unc in [(1.0, 6, False), (2.5, 6, False), (2.5, 5, True), (0.0, 4, True)]:
+        m, gnet = SamplerMock(0.9, 0.3), SamplerMock(0.5, -0.2)
+        s = rs.EDM_Sampler(m, gnet, num_solve_steps=N, guidance=guide)
+        out = s.sample(noise, text, -1.2, 1.6, uncond_text_emb=unc if use_unc else None)
+        out2 = s.sample(noise, text2, -1.2, 1.6, uncond_text_emb=unc if use_unc else None)
+        den = s.denoise(noise, torch.tensor(1.7), text, -1.2, 1.6, unc if use_unc else None)
+        cases.append(dict(guide=guide, N=N, use_unc=use_unc, out=out.clone(), out_text2=out2.clone(), denoise_at_1p7=den.clone()))
+    torch.save(dict(noise=noise, text=text, text2=text2, unc=unc, mock=dict(model=(0.9, 0.3), gnet=(0.5, -0.2)), tp=-1.2,
+                    softness=1.6, cases=cases), os.path.join(OUT, "sampler.pt"))
+    print("sampler:", [(c["guide"], c["N"], float(c["out"].abs().max())) for c in cases])
+
+
 def logger_fixture():
     """Records written by the reference's graphs/logger.py for a seeded 25-step stream (row N4)."""
     import json, tempfile
@@ -378,11 +416,19 @@ if __name__ == "__main__":
     if "--logger-only" in sys.argv:
         logger_fixture()
         sys.exit(0)
+    if "--sampler-only" in sys.argv:
+        sampler_fixture()
+        sys.exit(0)
+    if "--config1-only" in sys.argv:
+        wide_model(1, 8, 41)
+        sys.exit(0)
     if "--wide-only" not in sys.argv:
         components()
         full_model(1)
         full_model(2)
         logger_fixture()
+        sampler_fixture()
+    wide_model(1, 8, 41)                                  # BASELINE configs[0]: 3-channel, top-1, B = 8
     wide_model(2, 4, 21)
     wide_model(3, 4, 32)
     wide_model(4, 2, 23)

@@ -33,9 +33,15 @@ def golden_full(request):
     return torch.load(os.path.join(GOLDEN, f"full_config{request.param}.pt"), weights_only=False)
 
 
-@pytest.fixture(scope="session", params=[2, 3, 4])
+@pytest.fixture(scope="session")
+def golden_sampler():
+    import torch
+    return torch.load(os.path.join(GOLDEN, "sampler.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session", params=[1, 2, 3, 4])
 def golden_wide(request):
-    """BASELINE configs 2-4 at their real widths: outputs of the reference under oracle/recipe.py's weights/inputs."""
+    """BASELINE configs 1-4 at their real widths: outputs of the reference under oracle/recipe.py's weights/inputs."""
     import torch
     return torch.load(os.path.join(GOLDEN, f"wide_config{request.param}.pt"), weights_only=False)
 

@@ -115,7 +115,7 @@ def test_mp_conv_train_mutates_weights():
     close(conv.eval()(x), y)
 
 
-@pytest.mark.parametrize("name", ["self_time", "self_slice", "cross", "cross_text", "cross_time_q"])
+@pytest.mark.parametrize("name", ["self_time", "self_slice", "self_bicubic", "cross", "cross_text", "cross_time_q"])
 def test_attention_golden(golden_components, name):
     import models.model_internals as mi
     c = golden_components[f"attn_{name}"]
@@ -681,6 +681,107 @@ def test_sampler_runs_on_the_real_model(golden_full):
     sg = EDM_Sampler(model, model, num_solve_steps=4, use_graph=True)
     outg = sg.sample(noise, dev(g["text"][:2]), -1.2, 1.6)
     close_scaled(outg, out, 1e-5, msg="graph replay vs eager")
+
+
+class _FixtureMock(torch.nn.Module):
+    """oracle/make_golden.py's SamplerMock on the device: depends on sigma, text and transition_point/softness."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.num_experts = 4
+        self.a, self.b = a, b
+
+    def forward(self, x, sigma, text_emb, Unet_router_mask, Vit_router_mask, zeta, transition_point, softness, return_log_var=False):
+        assert sigma.ndim == 0 and Unet_router_mask.shape == (x.shape[0], 4) and zeta == 0
+        s = sigma.to(x.dtype)
+        t = text_emb.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+        return {"denoised": x * (self.a / (1.0 + s * s)) + self.b * t * torch.tanh(s) + 0.01 * transition_point * softness}
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sampler_matches_reference_fixture(golden_sampler, use_graph):
+    """Row N1: the product EDM_Sampler against trajectories the REFERENCE sampler produced (tests/golden/sampler.pt):
+    guidance 1.0 / 2.5 / 0.0, with and without an unconditional embedding, and -- for the hipGraph path -- a second prompt of the
+    same shape through the SAME captured graph (the replay must read the new text, not the captured one)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    from EDM_sampler import EDM_Sampler
+    g = golden_sampler
+    for c in g["cases"]:
+        m, gn = _FixtureMock(*g["mock"]["model"]).to(DEV), _FixtureMock(*g["mock"]["gnet"]).to(DEV)
+        s = EDM_Sampler(m, gn, num_solve_steps=c["N"], guidance=c["guide"], use_graph=use_graph)
+        unc = dev(g["unc"]) if c["use_unc"] else None
+        out = s.sample(dev(g["noise"]), dev(g["text"]), g["tp"], g["softness"], uncond_text_emb=unc)
+        close_scaled(out, c["out"], 2e-5, msg=f"guide={c['guide']} N={c['N']}")
+        out2 = s.sample(dev(g["noise"]), dev(g["text2"]), g["tp"], g["softness"], uncond_text_emb=unc)
+        close_scaled(out2, c["out_text2"], 2e-5, msg=f"second prompt, guide={c['guide']} N={c['N']}")
+        den = s.denoise(dev(g["noise"]), torch.tensor(1.7, device=DEV), dev(g["text"]), g["tp"], g["softness"], unc)
+        close_scaled(den, c["denoise_at_1p7"], 1e-5, msg="CFG lerp")
+
+
+def test_sampler_graph_follows_prompt_on_the_real_model(golden_full):
+    """two different same-shape prompts through one captured denoiser graph each equal their eager trajectory."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    from EDM_sampler import EDM_Sampler
+    from models import model_config2
+    g = golden_full
+    if g["variant"] != 2:
+        pytest.skip("model_config2 only")
+    model = load_into(model_config2.preconditioned_HDMOEM(**g["cfg"]), g["state"])
+    noise = torch.randn(2, 4, 16, 16, device=DEV)
+    ta, tb = dev(g["text"][:2]), dev(g["text"][2:4])
+    unc = dev(g["text"][4:6])
+    eager = EDM_Sampler(model, model, num_solve_steps=3, guidance=2.0)
+    graphed = EDM_Sampler(model, model, num_solve_steps=3, guidance=2.0, use_graph=True)
+    ea, eb = eager.sample(noise, ta, -1.2, 1.6, unc), eager.sample(noise, tb, -1.2, 1.6, unc)
+    assert float((ea - eb).abs().max()) > 1e-3                        # the prompts do matter
+    close_scaled(graphed.sample(noise, ta, -1.2, 1.6, unc), ea, 1e-5, msg="prompt A")
+    close_scaled(graphed.sample(noise, tb, -1.2, 1.6, unc), eb, 1e-5, msg="prompt B through the same graph")
+
+
+def test_sampler_config5_shape_graph_vs_eager():
+    """BASELINE configs[4]: EDM_sampler on 4x64x64 latents, 8 heterogeneous experts (incl. 7x7), bf16, hipGraph-captured step
+    -- small batch and N; the captured replay must reproduce the eager trajectory."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    import hdmoe_hip
+    from EDM_sampler import EDM_Sampler
+    from Utils import configs
+    from models import model_config2
+    from oracle.recipe import fill_state
+    bc = configs.BASELINE_CONFIGS[4]
+    kw = configs.model_kwargs(**bc["over"])
+    model = model_config2.preconditioned_HDMOEM(**kw)
+    model.load_state_dict(fill_state(model.state_dict(), 5))
+    model = model.to(DEV).eval()
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    try:
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        noise = torch.randn(2, 4, 64, 64, device=DEV, generator=gen)
+        text = torch.randn(2, 77, kw["text_emb_dim"], device=DEV, generator=gen)
+        eager = EDM_Sampler(model, model, num_solve_steps=3).sample(noise, text, -1.2, 1.6)
+        graphed = EDM_Sampler(model, model, num_solve_steps=3, use_graph=True).sample(noise, text, -1.2, 1.6)
+        assert eager.shape == (2, 4, 64, 64) and torch.isfinite(eager).all()
+        close_scaled(graphed, eager, 1e-5, msg="config 5 shape: graph replay vs eager")
+    finally:
+        hdmoe_hip.set_compute_dtype(torch.float32)
+
+
+def test_mask_generator_on_device(golden_components):
+    """Row N2: the product MaskGenerator on the GPU against the reference's masks (tests/golden/components.pt)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "heterogeneous-moe-for-diffusion-models_amd", "Utils"))
+    import utils as U
+    c = golden_components["mask_generator"]
+    mg = U.MaskGenerator(expert_attributes=c["attrs"], p_mean=c["p_mean"], p_std=c["p_std"], bandwidth=c["bandwidth"], max_bandwidth=0.8,
+                         min_active=1, total_steps=5000, step_size=0.1, noise_range=c["noise_range"], strat_band="step").to(DEV)
+    out = mg(dev(c["sigma"]), 0)
+    assert out.is_cuda and torch.equal(out.cpu(), c["out"])
 
 
 def test_fused_film_dropout_consistency():
