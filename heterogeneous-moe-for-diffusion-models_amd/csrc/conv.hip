@@ -18,6 +18,7 @@
 //                                 MI355X_MICROARCH "Global float atomics"); conv_wgrad_kernel for stride > 1
 #include <stdlib.h>
 #include "common.h"
+#include "conv_args.h"
 #include "hdmoe.h"
 
 namespace {
@@ -137,18 +138,6 @@ __global__ __launch_bounds__(128) void wprep_bwd_kernel(WprepBwdArgs a) {
 }
 
 // ------------------------------------------------------------------ conv forward / dgrad
-struct ConvArgs {
-  const void* x;      // [N][H][W][Cphys]
-  const void* w;      // [g][tap][Cout][Ipad]
-  void* y;            // [N][Ho][Wo][Cstore]
-  const void* res;    // optional [N][Ho][Wo][Cstore]:  y = alpha*acc + beta*res
-  const int* seg;     // [ngroups+1] row offsets or null
-  long wstride;
-  int N, H, W, Ho, Wo, Cin, Cphys, Ipad, Cout, Cstore, stride, ones, ngroups;
-  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
-  float alpha, beta;
-};
-
 DEVI int find_group(const int* seg, int ngroups, int n) {
   if (!seg) return 0;
   int g = -1;
@@ -177,7 +166,7 @@ template <typename T, int NB, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;                       // rows beyond 65535 come as further launches (a.n0)
   const int g = find_group(a.seg, a.ngroups, n);
   if (g < 0) return;
   const int HWo = a.Ho * a.Wo;
@@ -252,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_fwd2_kernel(ConvArgs a, int TH, int 
   T* sB = sA + (long)halo_cap * PSE;                         // [kw][32*NT][PSE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;                       // rows beyond 65535 come as further launches (a.n0)
   const int g = find_group(a.seg, a.ngroups, n);
   if (g < 0) return;
   const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
@@ -381,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_fwd3_kernel(ConvArgs a, int TH, int 
   T* sB = sA + (long)halo_cap * PSE;                         // [tg*kw][32*NT][PSE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;                       // rows beyond 65535 come as further launches (a.n0)
   const int g = find_group(a.seg, a.ngroups, n);
   if (g < 0) return;
   const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
@@ -1165,11 +1154,16 @@ __global__ __launch_bounds__(256, (MAXT <= 3 ? 2 : 1)) void conv_wgrad2_kernel(W
   }
 }
 
+constexpr int ROWS_PER_LAUNCH = 65535;                      // gridDim.y limit of the row-per-blockIdx.y kernels
+
 template <typename T, int NB>
-void launch_conv(const ConvArgs& a, bool vec, hipStream_t st) {
-  dim3 grid(cdiv((long)a.Ho * a.Wo, 128), a.N, cdiv(a.Cstore, 32 * NB));
-  if (vec) hipLaunchKernelGGL((conv_fwd_kernel<T, NB, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_fwd_kernel<T, NB, false>), grid, dim3(256), 0, st, a);
+void launch_conv(ConvArgs a, bool vec, hipStream_t st) {
+  for (int n0 = 0; n0 < a.N; n0 += ROWS_PER_LAUNCH) {
+    a.n0 = n0;
+    dim3 grid(cdiv((long)a.Ho * a.Wo, 128), a.N - n0 < ROWS_PER_LAUNCH ? a.N - n0 : ROWS_PER_LAUNCH, cdiv(a.Cstore, 32 * NB));
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<T, NB, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<T, NB, false>), grid, dim3(256), 0, st, a);
+  }
 }
 
 template <typename T>
@@ -1228,30 +1222,32 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
   if (!x || !w || !y || N < 0 || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return HDMOE_EINVAL;
   if (Ipad % 16 || Ipad < Cin || Cin != Cphys + (ones ? 1 : 0) || Cstore > Cout || stride < 1) return HDMOE_EINVAL;
   if (N == 0 || Ho * Wo == 0) return HDMOE_OK;
-  if (N > 65535) return HDMOE_EINVAL;
   ConvArgs a;
   a.x = x; a.w = w; a.y = y; a.res = res; a.seg = seg; a.wstride = wstride;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cphys = Cphys; a.Ipad = Ipad; a.Cout = Cout;
-  a.Cstore = Cstore; a.stride = stride; a.ones = ones; a.ngroups = ngroups; a.alpha = alpha; a.beta = beta;
+  a.Cstore = Cstore; a.stride = stride; a.ones = ones; a.ngroups = ngroups; a.alpha = alpha; a.beta = beta; a.n0 = 0;
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
     const int s = g < ngroups ? g : 0;
     a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
   }
   if (dtype != HDMOE_F32 && dtype != HDMOE_BF16) return HDMOE_EDTYPE;
-  if (stride == 1 && (long)Ho * Wo >= 64 && !getenv("HDMOE_CONV_V1")) {
+  {                                                        // k x k layers of the experts / trunks: persistent LDS-DMA kernel (conv6.hip)
+    const int rc = conv6_try_launch(a, nullptr, dtype, stream);
+    if (rc <= 0) return rc;
+  }
+  if (stride == 1 && (long)Ho * Wo >= 64) {
     // ---- v2: LDS-staged 256-pixel tiles
     const int PT = 4 * CV2_MT * 32;
     int maxkh = 1, maxkw = 1;
     for (int g = 0; g < ngroups; ++g) { if (kh[g] > maxkh) maxkh = kh[g]; if (kw[g] > maxkw) maxkw = kw[g]; }
     const int esz = dtype == HDMOE_BF16 ? 2 : 4;
-    static const bool no_v5 = getenv("HDMOE_CONV_V3") != nullptr;
-    const bool v5ok = !no_v5 && !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
+    const bool v5ok = !ones && Cstore % 4 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)res % 16 == 0 && (uintptr_t)w % 16 == 0;
     // Tile = whole image rows, or (v5 only, images wider than 32 with a real kernel window) 8 x 32 blocks: a 4 x 64 tile of a
     // 7x7 layer needs a 10 x 70 halo, the 8 x 32 block 14 x 38.  tile2d != 0 tells the kernel the tile is not a linear pixel run.
     const int NTq = Cstore <= 32 ? 1 : 2;
     const bool vecq = Cphys % (16 / esz) == 0 && (uintptr_t)x % 16 == 0;
     // (only when the v5 launch below is certain: the older kernels assume linear tiles)
-    const bool tile2d = v5ok && vecq && Ho >= 8 && Wo > 32 && Wo % 32 == 0 && maxkh * maxkw > 1 && !getenv("HDMOE_CONV_V2") &&
+    const bool tile2d = v5ok && vecq && Ho >= 8 && Wo > 32 && Wo % 32 == 0 && maxkh * maxkw > 1 &&
                         (8 + maxkh - 1) * (32 + maxkw - 1) * 4 <= 9 * 256 && maxkw * 32 * NTq <= 576 &&
                         (long)maxkh * maxkw * Cout * Ipad < (1l << 26) && (long)H * W * Cphys < (1l << 30) &&
                         (size_t)80 * ((8 + maxkh - 1) * (32 + maxkw - 1) + maxkw * 32 * NTq) <= 80 * 1024;
@@ -1267,7 +1263,8 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     // v5 <= 576 px (9 chunks/thread: 7x7 experts, whose halo of a 256-pixel tile is 14 x 38 or 22 x 22 pixels)
     const int halo_max = v5ok ? 9 * 256 : 7 * 256;
     if (vec && halo_cap * 4 <= halo_max && maxkw * 32 * NT <= 576 && (long)maxkh * maxkw * Cout * Ipad < (1l << 26) &&
-        (long)H * W * Cphys < (1l << 30) && !getenv("HDMOE_CONV_V2")) {
+        (long)H * W * Cphys < (1l << 30) &&
+        (long)halo_cap * (TW + maxkw - 1) < (1l << 20)) {   // the kernels' (px * magic) >> 20 halo decode is exact while px * HWp < 2^20
       // a workgroup may use up to 80 KB of LDS under v5 (two still share a CU): needed by 7x7 experts with 64-channel tiles
       const size_t cap = v5ok ? 80 * 1024 : 64 * 1024;
       int tg = 576 / (maxkw * 32 * NT);
@@ -1300,12 +1297,15 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
         return hdmoe_launch_status();
       }
       if (lds3 <= 64 * 1024 && halo_cap * 4 <= 7 * 256) {
-        if (dtype == HDMOE_F32) {
-          if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<float, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
-          else hipLaunchKernelGGL((conv_fwd3_kernel<float, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
-        } else {
-          if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
-          else hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+        for (int n0 = 0; n0 < N; n0 += ROWS_PER_LAUNCH) {
+          a.n0 = n0; grid.y = N - n0 < ROWS_PER_LAUNCH ? N - n0 : ROWS_PER_LAUNCH;
+          if (dtype == HDMOE_F32) {
+            if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<float, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+            else hipLaunchKernelGGL((conv_fwd3_kernel<float, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+          } else {
+            if (NT == 1) hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 1>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+            else hipLaunchKernelGGL((conv_fwd3_kernel<bf16, 2>), grid, dim3(256), lds3, stream, a, TH, TW, tiles_x, halo_cap, tg);
+          }
         }
         return hdmoe_launch_status();
       }
@@ -1314,8 +1314,11 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
 #define CV2_LAUNCH(TT, NTv)                                                                                                   \
   do { if (vec) hipLaunchKernelGGL((conv_fwd2_kernel<TT, NTv, true>), grid, dim3(256), lds, stream, a, TH, TW, tiles_x, halo_cap);  \
        else hipLaunchKernelGGL((conv_fwd2_kernel<TT, NTv, false>), grid, dim3(256), lds, stream, a, TH, TW, tiles_x, halo_cap); } while (0)
-      if (dtype == HDMOE_F32) { if (NT == 1) CV2_LAUNCH(float, 1); else CV2_LAUNCH(float, 2); }
-      else { if (NT == 1) CV2_LAUNCH(bf16, 1); else CV2_LAUNCH(bf16, 2); }
+      for (int n0 = 0; n0 < N; n0 += ROWS_PER_LAUNCH) {
+        a.n0 = n0; grid.y = N - n0 < ROWS_PER_LAUNCH ? N - n0 : ROWS_PER_LAUNCH;
+        if (dtype == HDMOE_F32) { if (NT == 1) CV2_LAUNCH(float, 1); else CV2_LAUNCH(float, 2); }
+        else { if (NT == 1) CV2_LAUNCH(bf16, 1); else CV2_LAUNCH(bf16, 2); }
+      }
       return hdmoe_launch_status();
     }
   }

@@ -1,0 +1,32 @@
+// Argument block shared by the conv forward / dgrad kernels (conv.hip: v5 and the odd-shape kernels; conv6.hip: the
+// persistent LDS-DMA pipelined kernel).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const void* x;      // [N][H][W][Cphys]
+  const void* w;      // [g][tap][Cout][Ipad]
+  void* y;            // [N][Ho][Wo][Cstore]
+  const void* res;    // optional [N][Ho][Wo][Cstore]:  y = alpha*acc + beta*res
+  const int* seg;     // [ngroups+1] row offsets or null
+  long wstride;
+  int N, H, W, Ho, Wo, Cin, Cphys, Ipad, Cout, Cstore, stride, ones, ngroups;
+  int n0;             // first row of this launch (row-per-blockIdx.y kernels: 65535 rows per launch)
+  int kh[HDMOE_MAX_GROUPS], kw[HDMOE_MAX_GROUPS], pt[HDMOE_MAX_GROUPS], pl[HDMOE_MAX_GROUPS];
+  float alpha, beta;
+};
+
+// Fused pro-/epilogue of the conv6 kernels (all optional):
+//   in_scale/in_shift [N][Cin] fp32 + in_relu: the staged input is relu(x * scale[n][c] + shift[n][c]) -- GroupNorm(1,C) + ReLU of the
+//   producing layer folded into this layer's staging pass (Router.hard_route, reference model_components.py:100-112);
+//   stats [N][2] fp32 (caller zeroes): per-sample sum and sum of squares of the fp32 outputs, accumulated for the NEXT GroupNorm.
+struct ConvFuse {
+  const float* in_scale;
+  const float* in_shift;
+  float* stats;
+  int in_relu;
+};
+
+// Returns HDMOE_OK after launching, a negative status on a launch error, or 1 when the shape is outside conv6's domain
+// (the caller then takes the general kernels).
+int conv6_try_launch(const ConvArgs& a, const ConvFuse* fuse, int dtype, hipStream_t stream);

@@ -65,6 +65,10 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
                      int Ho, int Wo, int Cin, int Cphys, int Cout, int stride, int ones, const int* kh, const int* kw,
                      const int* pt, const int* pl, int dtype, HS stream);
 
+/* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
+ * (tag << 56 | s_memtime) of every later launch; NULL switches it off (tools/conv6_check.py --stamps). */
+int hdmoe_conv6_debug_stamps(void* buf);
+
 /* Multi-tensor weight bank: one prep launch per forward and one gradient-finish launch per backward for ALL MP_Conv weights
  * of a model.  descs: device array of descriptors (layout = hdmoe_wbank_desc_bytes() bytes each, see csrc/wbank.hip);
  * rows: device int32 pairs (descriptor index, output-channel row), one workgroup per pair. */
