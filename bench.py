@@ -26,7 +26,9 @@ for p in (PKG, os.path.join(PKG, "Utils"), ROOT):
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MFMA_PEAK = {"bfloat16": 2500.0, "float32": 157.3}     # dense TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
+# dense TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters".  split_bf16 = fp32 tensors computed as three bf16 MFMAs per
+# product (csrc/conv6s.hip): its peak in ALGORITHMIC (fp32-equivalent) FLOP/s is a third of the bf16 peak.
+MFMA_PEAK = {"bfloat16": 2500.0, "float32": 157.3, "split_bf16": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 
 

@@ -11,6 +11,7 @@
 // dtype codes of the C ABI
 #define HDMOE_F32 0
 #define HDMOE_BF16 1
+#define HDMOE_F32S 2     /* fp32 tensors, split-bf16 arithmetic: weight images are bf16 [hi | lo] planes */
 
 #define HDMOE_MAX_GROUPS 8
 #define MP_SILU_DIV 0.596f

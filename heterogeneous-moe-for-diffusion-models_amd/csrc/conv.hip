@@ -34,6 +34,7 @@ struct WprepArgs {
   int O, I, Ipad, Opad;
   float gain_val;
   int normalize, mutate, flip;
+  long wf_plane, wd_plane;               // > 0: split-bf16 images (T = bf16): the lo plane lies this many elements behind the hi plane
 };
 
 template <typename T>
@@ -74,16 +75,23 @@ __global__ __launch_bounds__(128) void wprep_fwd_kernel(WprepArgs a) {
   }
   for (int e = tid; e < fan; e += blockDim.x) {
     const int i = e / taps, t = e % taps;
-    const T v = from_f<T>(w[e] * scale);
-    wf[((long)t * a.O + o) * a.Ipad + i] = v;
-    if (wd) {
-      const int td = a.flip ? taps - 1 - t : t;
-      wd[((long)td * a.I + i) * a.Opad + o] = v;
+    const float vf = w[e] * scale;
+    const T v = from_f<T>(vf);
+    const long fi = ((long)t * a.O + o) * a.Ipad + i;
+    wf[fi] = v;
+    const int td = a.flip ? taps - 1 - t : t;
+    const long di = ((long)td * a.I + i) * a.Opad + o;
+    if (wd) wd[di] = v;
+    if (a.wf_plane > 0) {                                   // split-bf16: lo = bf16(v - hi)
+      const T lo = from_f<T>(vf - to_f(v));
+      wf[a.wf_plane + fi] = lo;
+      if (wd) wd[a.wd_plane + di] = lo;
     }
   }
   for (int e = tid; e < (a.Ipad - a.I) * taps; e += blockDim.x) {
     const int t = e / (a.Ipad - a.I), i = a.I + e % (a.Ipad - a.I);
     wf[((long)t * a.O + o) * a.Ipad + i] = from_f<T>(0.f);
+    if (a.wf_plane > 0) wf[a.wf_plane + ((long)t * a.O + o) * a.Ipad + i] = from_f<T>(0.f);
   }
 }
 
@@ -1192,9 +1200,14 @@ int hdmoe_wprep_fwd(float* const* w_raw, const float* const* gain_ptr, float gai
   a.wf = wf; a.wd = wd; a.wf_stride = wf_stride; a.wd_stride = wd_stride;
   a.O = O; a.I = I; a.Ipad = Ipad; a.Opad = wd ? Opad : O; a.gain_val = gain_val;
   a.normalize = normalize; a.mutate = mutate; a.flip = flip;
+  a.wf_plane = a.wd_plane = 0;
+  if (dtype == HDMOE_F32S) {                               // planes [hi | lo], each holding all groups
+    if (Opad != O && wd) return HDMOE_EINVAL;              // (the split kernels take unpadded channel counts only)
+    a.wf_plane = (long)ngroups * wf_stride; a.wd_plane = (long)ngroups * wd_stride;
+  }
   dim3 grid(wd ? (Opad > O ? Opad : O) : O, ngroups);
   if (dtype == HDMOE_F32) hipLaunchKernelGGL(wprep_fwd_kernel<float>, grid, dim3(128), 0, stream, a);
-  else if (dtype == HDMOE_BF16) hipLaunchKernelGGL(wprep_fwd_kernel<bf16>, grid, dim3(128), 0, stream, a);
+  else if (dtype == HDMOE_BF16 || dtype == HDMOE_F32S) hipLaunchKernelGGL(wprep_fwd_kernel<bf16>, grid, dim3(128), 0, stream, a);
   else return HDMOE_EDTYPE;
   return hdmoe_launch_status();
 }
@@ -1229,6 +1242,10 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
     const int s = g < ngroups ? g : 0;
     a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
+  }
+  if (dtype == HDMOE_F32S) {                               // fp32 tensors on the bf16 pipe (conv6s.hip); callers check the domain first
+    const int rc = conv6_split_try_launch(a, (long)ngroups * wstride, nullptr, stream);
+    return rc == 1 ? HDMOE_EINVAL : rc;
   }
   if (dtype != HDMOE_F32 && dtype != HDMOE_BF16) return HDMOE_EDTYPE;
   {                                                        // k x k layers of the experts / trunks: persistent LDS-DMA kernel (conv6.hip)

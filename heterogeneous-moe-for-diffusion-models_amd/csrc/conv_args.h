@@ -30,3 +30,6 @@ struct ConvFuse {
 // Returns HDMOE_OK after launching, a negative status on a launch error, or 1 when the shape is outside conv6's domain
 // (the caller then takes the general kernels).
 int conv6_try_launch(const ConvArgs& a, const ConvFuse* fuse, int dtype, hipStream_t stream);
+
+// Split-bf16 variant for fp32 tensors (conv6s.hip): w = bf16 [hi | lo][g][tap][Cout][Cin], `wplane_elems` elements per plane.
+int conv6_split_try_launch(const ConvArgs& a, long wplane_elems, const ConvFuse* fuse, hipStream_t stream);

@@ -11,6 +11,7 @@ struct __attribute__((aligned(8))) WBDesc {   // mirrored byte-for-byte by hdmoe
   unsigned long long w_raw, wf, wd, G, dw;   // device addresses
   int O, I, kh, kw, Ipad, Opad, dtype, normalize, mutate_ok, pad0;
   float gain, out_scale;
+  long long wf_plane, wd_plane;              // dtype == HDMOE_F32S: elements between the hi and the lo bf16 image
 };
 
 template <typename T> DEVI void wb_store(void* base, long idx, float v) { ((T*)base)[idx] = from_f<T>(v); }
@@ -47,6 +48,11 @@ __global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, co
     const long di = ((long)(taps - 1 - t) * d.I + i) * d.Opad + o;
     if (f32) { wb_store<float>((void*)d.wf, fi, v); if (d.wd) wb_store<float>((void*)d.wd, di, v); }
     else { wb_store<bf16>((void*)d.wf, fi, v); if (d.wd) wb_store<bf16>((void*)d.wd, di, v); }
+    if (d.dtype == HDMOE_F32S) {                             // split-bf16: the lo plane holds bf16(v - hi)
+      const float lo = v - (float)(bf16)v;
+      wb_store<bf16>((void*)d.wf, d.wf_plane + fi, lo);
+      if (d.wd) wb_store<bf16>((void*)d.wd, d.wd_plane + di, lo);
+    }
   }
 }
 

@@ -21,7 +21,7 @@ from ._lib import call, dtype_code, lib
 _DESC = np.dtype([("w_raw", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("G", "<u8"), ("dw", "<u8"),
                   ("O", "<i4"), ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("Ipad", "<i4"), ("Opad", "<i4"),
                   ("dtype", "<i4"), ("normalize", "<i4"), ("mutate_ok", "<i4"), ("pad0", "<i4"),
-                  ("gain", "<f4"), ("out_scale", "<f4")])
+                  ("gain", "<f4"), ("out_scale", "<f4"), ("wf_plane", "<i8"), ("wd_plane", "<i8")])
 
 ACTIVE: Optional["WeightBank"] = None
 
@@ -116,8 +116,10 @@ class WeightBank:
         goff = 0
         for ent in ents:
             G = len(ent.params)
-            ent.wf = torch.zeros(G * ent.wstride, dtype=ent.dtype, device=dev)        # pads stay zero for ever
-            ent.wd = torch.zeros(G * ent.wdstride, dtype=ent.dtype, device=dev)
+            # "split": fp32 layer computed as split bf16 -- bf16 images with a hi and a lo plane (csrc/conv6s.hip)
+            wdt, planes = (torch.bfloat16, 2) if ent.dtype == "split" else (ent.dtype, 1)
+            ent.wf = torch.zeros(planes * G * ent.wstride, dtype=wdt, device=dev)     # pads stay zero for ever
+            ent.wd = torch.zeros(planes * G * ent.wdstride, dtype=wdt, device=dev)
             ent.G = []
             for g in range(G):
                 ent.G.append(self._gflat[goff:goff + ent.gsizes[g]])
@@ -146,14 +148,17 @@ class WeightBank:
         rows = []
         di = 0
         for ent in ents:
-            esz = 2 if ent.dtype == torch.bfloat16 else 4
+            esz = 4 if ent.dtype == torch.float32 else 2
+            G = len(ent.params)
             for g, p in enumerate(ent.params):
                 d = descs[di]
                 d["w_raw"], d["dw"], d["G"] = p.data_ptr(), p.grad.data_ptr(), ent.G[g].data_ptr()
                 d["wf"] = ent.wf.data_ptr() + g * ent.wstride * esz
                 d["wd"] = ent.wd.data_ptr() + g * ent.wdstride * esz
                 d["O"], d["I"], d["kh"], d["kw"] = ent.O, ent.I, ent.khs[g], ent.kws[g]
-                d["Ipad"], d["Opad"], d["dtype"], d["normalize"] = ent.Ipad, ent.Opad, dtype_code(ent.dtype), int(ent.normalize)
+                d["Ipad"], d["Opad"], d["normalize"] = ent.Ipad, ent.Opad, int(ent.normalize)
+                d["dtype"] = 2 if ent.dtype == "split" else dtype_code(ent.dtype)
+                d["wf_plane"], d["wd_plane"] = G * ent.wstride, G * ent.wdstride
                 d["mutate_ok"], d["gain"], d["out_scale"] = 1, ent.gain, ent.alpha
                 rows.extend((di, o) for o in range(ent.O))
                 di += 1

@@ -106,8 +106,24 @@ def _timed(kind: str, info: dict, name: str, *args):
     PROFILE.append((kind, info, s, e))
 
 
-def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys):
+def _conv6_domain(x, Ho, Wo, O, I, Cstore, khs, kws, cphys, split):
+    """(kernel name, dtype label) when the launch goes to the conv6 kernels (csrc/conv6.hip / conv6s.hip), else None."""
+    if Cstore != O or cphys != I or I % 32 or O % 32 or not (Wo == 16 or Wo % 32 == 0) or Ho < 8:
+        return None
+    if split:
+        return (f"conv6_split_kernel<{2 if O % 64 == 0 else 1}>", "split_bf16") if all(k == 3 for k in khs) else None
+    if x.dtype != torch.bfloat16 or any(a != b or a not in (3, 5, 7) for a, b in zip(khs, kws)):
+        return None
+    return "conv6_bf16_kernel", "bfloat16"
+
+
+def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys, split=False):
     """Shape record of one launch + the kernel instantiation hdmoe_conv_fwd will pick (mirrors csrc/conv.hip)."""
+    c6 = _conv6_domain(x, Ho, Wo, O, I, Cstore, khs, kws, cphys, split)
+    if c6 is not None:
+        tname = "float" if x.dtype == torch.float32 else "__bf16"
+        return dict(dtype=c6[1], seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)], fwd_name=c6[0],
+                    wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws)))))
     esz = x.element_size()
     vec = cphys % (16 // esz) == 0
     tname = "float" if x.dtype == torch.float32 else "__bf16"
@@ -168,7 +184,7 @@ class _MPConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, seg, meta, *tensors):
-        (G, gain_val, alpha, beta, ones, training, normalize) = meta
+        (G, gain_val, alpha, beta, ones, training, normalize, split) = meta
         weights, gains = tensors[:G], list(tensors[G:]) or None
         x = _c(x)
         N, H, W, Cphys = x.shape
@@ -189,31 +205,33 @@ class _MPConvFn(torch.autograd.Function):
         Opad = (O + 15) // 16 * 16
         taps = max(a * b for a, b in zip(khs, kws))
         wstride, wdstride = taps * O * Ipad, taps * I * Opad
+        # split: fp32 tensors, split-bf16 arithmetic (csrc/conv6s.hip) -- weight images are bf16 [hi | lo] planes, dtype code 2
+        wdt, planes, dtc = (torch.bfloat16, 2, F32S) if split else (x.dtype, 1, _dt(x))
         ent = None
         if _bank.ACTIVE is not None and gains is None:
-            ent = _bank.ACTIVE.lookup(weights, x.dtype, gain_val, alpha, normalize)
+            ent = _bank.ACTIVE.lookup(weights, "split" if split else x.dtype, gain_val, alpha, normalize)
         if ent is not None:                                   # images already prepared by the bank's single launch
             wf, wd = ent.wf, ent.wd
         else:
-            wf = torch.empty(G * wstride, dtype=x.dtype, device=x.device)
+            wf = torch.empty(planes * G * wstride, dtype=wdt, device=x.device)
             # the flipped dgrad image is produced by the same prep launch when the input needs a gradient
-            wd = torch.empty(G * wdstride, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+            wd = torch.empty(planes * G * wdstride, dtype=wdt, device=x.device) if ctx.needs_input_grad[0] else None
             call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
-                 1 if normalize else 0, 1 if training else 0, 1, _dt(x))
+                 1 if normalize else 0, 1 if training else 0, 1, dtc)
         ctx.wd = wd
         ctx.ent = ent
         ctx.bank = _bank.ACTIVE if ent is not None else None
         y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
-        _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
-               seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
+        _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys, split), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
+               seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, dtc)
         ctx.save_for_backward(x, seg, *tensors)
-        ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None)
+        ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None, split)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, seg, *tensors = ctx.saved_tensors
-        G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, has_res = ctx.meta
+        G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, has_res, split = ctx.meta
         weights, gains = tensors[:G], list(tensors[G:]) or None
         dy = _c(dy)
         N, H, W, Cphys = x.shape
@@ -231,8 +249,8 @@ class _MPConvFn(torch.autograd.Function):
             pt_d = [kh - 1 - p for kh, p in zip(khs, pts)]
             pl_d = [kw - 1 - p for kw, p in zip(kws, pts)]
             # dgrad: conv over dy (O channels) with the flipped kernel; logical out channels I, stored Cphys
-            _timed("conv_fwd", _conv_info(dy, seg, N, H, W, I, O, Cphys, khs, kws, O), "hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0,
-                   seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0, khs, kws, pt_d, pl_d, _dt(x))
+            _timed("conv_fwd", _conv_info(dy, seg, N, H, W, I, O, Cphys, khs, kws, O, split), "hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0,
+                   seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0, khs, kws, pt_d, pl_d, F32S if split else _dt(x))
         if has_res and nig[1]:
             dres = torch.empty_like(dy)
             call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
@@ -263,8 +281,24 @@ class _MPConvFn(torch.autograd.Function):
         return (dx, dres, None, None, *dws, *dgs)
 
 
+F32S = 2                                  # C-ABI dtype code: fp32 tensors, split-bf16 arithmetic (include/hdmoe.h HDMOE_F32S)
+# The fp32 router trunks run on the bf16 matrix pipe as split-bf16 (3 MFMAs per product, ~1e-5 relative): HDMOE_ROUTER_SPLIT=0
+# keeps them on the fp32-input MFMA kernels.
+ROUTER_SPLIT = _os.environ.get("HDMOE_ROUTER_SPLIT", "1") != "0"
+
+
+def _split_ok(x4: Tensor, ws, ones: bool) -> bool:
+    """Domain of the split-bf16 conv kernels (csrc/conv6s.hip); mirrored here because the weight image format depends on it."""
+    if x4.dtype != torch.float32 or ones or x4.ndim != 4:
+        return False
+    _, H, W, C = x4.shape
+    O = ws[0].shape[0]
+    return (all(w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3 for w in ws) and C % 32 == 0 and O % 32 == 0
+            and (W == 16 or W % 32 == 0) and H >= 8)
+
+
 def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: Optional[Tensor] = None, alpha: float = 1.0,
-            beta: float = 0.0, ones: bool = False, training: bool = False, normalize: bool = True) -> Tensor:
+            beta: float = 0.0, ones: bool = False, training: bool = False, normalize: bool = True, split: bool = False) -> Tensor:
     """Magnitude-preserving conv / linear (reference MP_Conv.forward, model_internals.py:253-275).
 
     ``x``: (N,H,W,C) -> (N,Ho,Wo,O);  (N,S,C) -> (N,S,O);  (M,C) -> (M,O).  ``weights``: a tensor, or a list of
@@ -295,7 +329,8 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
         x4 = x
     if res is not None:
         res = res.reshape(x4.shape[0], x4.shape[1], x4.shape[2], -1)
-    meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize))
+    split = bool(split) and _split_ok(x4, ws, ones)
+    meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize), split)
     y = _MPConvFn.apply(x4, res, seg, meta, *ws, *gts)
     return y.reshape(*shape[:-1], y.shape[-1])
 

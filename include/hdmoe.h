@@ -29,6 +29,7 @@ extern "C" {
 #define HDMOE_ELAUNCH (-3)
 #define HDMOE_F32 0
 #define HDMOE_BF16 1
+#define HDMOE_F32S 2 /* fp32 activations computed as split bf16 (hi + lo, three MFMAs per product): weight images = bf16 [hi | lo] planes */
 #define HDMOE_MAX_GROUPS 8
 #endif
 

@@ -456,6 +456,30 @@ def test_mp_conv_vs_oracle(dtype, rel, cin, cout, k, hw):
     close_scaled(wd.grad, wr.grad, rel, msg="dw")
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(32, 64, 32, 5), (128, 128, 32, 3), (128, 64, 16, 6), (64, 32, 64, 2)])
+def test_split_bf16_conv_vs_fp64(cin, cout, hw, n):
+    """Router-trunk convs in bf16 compute mode: fp32 tensors on the bf16 matrix pipe as split bf16 (hi + lo, three MFMAs per product,
+    csrc/conv6s.hip).  Against an fp64 CPU conv the error is ~5e-6 of the tensor's max (fp32 MFMA: ~1e-7; plain bf16: ~4e-3) for the
+    forward and dgrad; wgrad stays on the fp32 kernel."""
+    import torch.nn.functional as F
+    from hdmoe_hip import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, hw, hw, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    go = torch.randn(n, hw, hw, cout, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(DEV))
+    y = ops.mp_conv(xd, wd, 1.0, split=True)                      # normalised weights, as MP_Conv
+    y.backward(go.to(DEV))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    wn = w64 / (1e-4 + w64.flatten(1).norm(dim=1).view(-1, 1, 1, 1) / math.sqrt(cin * 9)) / math.sqrt(cin * 9)
+    y64 = F.conv2d(F.pad(x64.permute(0, 3, 1, 2), (1, 1, 1, 1)), wn).permute(0, 2, 3, 1)
+    (y64 * go.double()).sum().backward()
+    close_scaled(y, y64.float(), 2e-5, msg="split fwd")
+    close_scaled(xd.grad, x64.grad.float(), 2e-5, msg="split dgrad")
+    close_scaled(wd.grad, w64.grad.float(), 1e-5, msg="wgrad (fp32 kernel)")
+
+
 @pytest.mark.parametrize("rows", [2045 * 128, 262144, 3000 * 128 + 64])
 def test_pointwise_wgrad_on_a_long_flattened_row(rows):
     """BASELINE-size token counts: an ungrouped 1x1 layer runs as ONE flattened row of B*S pixels (262144 at B = 256, S = 1024,

@@ -58,6 +58,53 @@ def check(N, R, Cin, Cout, ks, split, with_res, seed=0):
     return ok
 
 
+def check_split(N, R, Cin, Cout, with_res=False, seed=0):
+    """fp32 tensors through the split-bf16 kernel (csrc/conv6s.hip) against an fp64 CPU conv: expect ~1e-5 relative."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, R, R, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xd = x.to(dev).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(dev))
+    y = ops.mp_conv(xd, wd, 1.0, normalize=False, split=True)
+    go = torch.randn(N, R, R, Cout, generator=g)
+    y.backward(go.to(dev))
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(F.pad(x64.permute(0, 3, 1, 2), (1, 1, 1, 1)), w64).permute(0, 2, 3, 1)
+    (y64 * go.double()).sum().backward()
+    e1 = float((y.detach().cpu().double() - y64.detach()).abs().max() / y64.abs().max())
+    e2 = float((xd.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max())
+    e3 = float((wd.grad.cpu().double() - w64.grad).abs().max() / w64.grad.abs().max())
+    ok = e1 < 5e-5 and e2 < 5e-5 and e3 < 5e-5
+    print(f"{'ok ' if ok else 'BAD'} split N={N} R={R} {Cin}->{Cout}: fwd {e1:.2e} dgrad {e2:.2e} wgrad {e3:.2e}", flush=True)
+    return ok
+
+
+def time_split(N, R, Cin, Cout, iters=10):
+    x = torch.randn(N, R, R, Cin, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev)
+    from hdmoe_hip._lib import call
+    res = {}
+    for name, code in (("split", 2), ("fp32", 0)):
+        wstride = 9 * Cout * Cin
+        wf = torch.empty((2 if code == 2 else 1) * wstride, dtype=torch.bfloat16 if code == 2 else torch.float32, device=dev)
+        call("hdmoe_wprep_fwd", [w], None, 1.0, [3], [3], 1, Cout, Cin, Cin, Cout, wf, wstride, None, 0, 1, 0, 1, code)
+        y = torch.empty(N, R, R, Cout, device=dev)
+        args = (x, wf, y, None, 1.0, 0.0, None, 1, wstride, N, R, R, R, R, Cin, Cin, Cin, Cout, Cout, 1, 0, [3], [3], [1], [1], code)
+        for _ in range(2):
+            call("hdmoe_conv_fwd", *args)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            call("hdmoe_conv_fwd", *args)
+        e.record()
+        torch.cuda.synchronize()
+        res[name] = 1e3 * s.elapsed_time(e) / iters
+    fl = 2.0 * N * R * R * Cout * Cin * 9
+    print(f"time split N={N} R={R} {Cin}->{Cout}: split {res['split']:8.1f} us ({fl / res['split'] / 1e6:6.1f} TF/s)   fp32 MFMA {res['fp32']:8.1f} us ({fl / res['fp32'] / 1e6:6.1f} TF/s)", flush=True)
+
+
 def timeit(N, R, Cin, Cout, ks, iters=20):
     x = torch.randn(N, R, R, Cin, device=dev).bfloat16()
     wd = [torch.randn(Cout, Cin, k, k, device=dev) for k in ks]
@@ -142,6 +189,17 @@ def stamps(N, R, Cin, Cout, ks):
 
 if __name__ == "__main__":
     hdmoe_hip.lib()
+    if "--split" in sys.argv:
+        good = True
+        good &= check_split(3, 32, 32, 64)
+        good &= check_split(5, 32, 64, 128)
+        good &= check_split(4, 16, 128, 128)
+        good &= check_split(70, 32, 128, 128, seed=3)
+        good &= check_split(9, 64, 64, 32)
+        print("SPLIT ALL OK" if good else "SPLIT FAILURES", flush=True)
+        for (Ci, Co) in [(32, 64), (64, 128), (128, 128), (128, 64), (64, 32)]:
+            time_split(256, 32, Ci, Co)
+        sys.exit(0 if good else 1)
     if "--stamps" in sys.argv:
         stamps(512, 32, 32, 32, [3]); stamps(512, 16, 64, 64, [5]); stamps(512, 32, 64, 64, [3, 3, 5, 5])
         sys.exit(0)
