@@ -329,7 +329,10 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: model_config{bc['module']} preconditioned_HDMOEM, "
                                    f"{kw['IN_in_channels']}x{kw['IN_img_resolution']}x{kw['IN_img_resolution']} latents, "
                                    f"{kw['num_experts']} experts top-{kw['top_k']}, per-GPU batch {B}, train mode",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "step": "fwd + EDM_LOSS + bwd"
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
+                       "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else "hipGraph replay", "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "grad_bytes": buckets.nbytes()},
             "roofline": roof, "cpu_baseline": cpu,

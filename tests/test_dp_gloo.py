@@ -96,3 +96,80 @@ def test_grad_buckets_world2_gloo(side_streams):
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The REAL parameter layout: GradBuckets over preconditioned_HDMOEM (CPU-constructed; the HIP kernels are not involved -- gradients
+# are synthetic, written straight into the bucket views the way autograd / the weight bank write them on the GPU).
+def _hdmoem_worker(rank, world, port, q, side_streams):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "heterogeneous-moe-for-diffusion-models_amd"))
+    from hdmoe_hip import ops
+    from hdmoe_hip.dp import GradBuckets
+    from models import model_config2
+    ops.SIDE_STREAMS = side_streams
+    torch.manual_seed(1)
+    cfg = dict(IN_in_channels=4, IN_img_resolution=16, internal_channels=8, time_emb_dim=16, text_emb_dim=32, num_experts=4, top_k=2,
+               Fourier_bandwidth=1.0, VIT_num_blocks=1, VIT_patch_sizes=[2, 4, 4, 8], VIT_num_groups=2, VIT_num_heads=2, VIT_emb_size=8,
+               Unet_num_blocks=1, Unet_channel_mult=[1, 2], Unet_kernel_sizes=[(3, 3), (3, 3), (5, 5), (5, 5)], Unet_model_channels=8,
+               Unet_channel_mult_emb=2, sigma_data=0.5, log_var_channels=8)
+    model = model_config2.preconditioned_HDMOEM(**cfg)
+    names = [n for n, _ in model.named_parameters()]
+    buckets = GradBuckets(model, bucket_mb=0.25)
+    assert buckets.nbytes() == 4 * sum(p.numel() for p in model.parameters())
+    if side_streams:
+        assert len(buckets.buckets) == 1 and not buckets.eager
+    else:
+        assert len(buckets.buckets) >= 3 and buckets.eager
+    # every parameter's .grad is a view into exactly one bucket, in reverse registration order
+    spans = sorted((p.grad.data_ptr(), p.grad.numel()) for p in model.parameters())
+    for (a0, n0), (a1, _) in zip(spans, spans[1:]):
+        assert a0 + 4 * n0 <= a1
+    unused = "net.Unet_experts.2." if rank == 1 else None            # rank 1 routes nothing to U-Net expert 2
+    for step in range(2):
+        buckets.zero_grad()
+        g = torch.Generator().manual_seed(100 * step + rank)
+        mine = {}
+        # gradients land in reverse registration order, like backward; the unused expert's slice is never touched
+        for n, p in reversed(list(model.named_parameters())):
+            if unused and n.startswith(unused):
+                mine[n] = torch.zeros_like(p)
+                continue
+            mine[n] = torch.randn(p.shape, generator=g)
+            p.grad.add_(mine[n])                                     # AccumulateGrad into the bucket view
+            for h in p._post_accumulate_grad_hooks.values():         # what autograd calls after accumulating
+                h(p)
+        buckets.finish()
+        # reference: average of both ranks' synthetic gradients
+        for n, p in model.named_parameters():
+            ref = torch.zeros_like(p)
+            for r in range(world):
+                gr = torch.Generator().manual_seed(100 * step + r)
+                vals = {}
+                for n2, p2 in reversed(list(model.named_parameters())):
+                    if r == 1 and n2.startswith("net.Unet_experts.2."):
+                        vals[n2] = torch.zeros_like(p2)
+                    else:
+                        vals[n2] = torch.randn(p2.shape, generator=gr)
+                ref += vals[n] / world
+            torch.testing.assert_close(p.grad, ref, rtol=1e-6, atol=1e-7)
+    q.put((rank, "ok", len(names)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("side_streams", [False, True])
+def test_grad_buckets_over_the_real_hdmoem_parameter_list(side_streams):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hdmoem_worker, args=(r, 2, port, q, side_streams)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = [q.get(timeout=5) for _ in range(2)]
+    assert sorted(r for r, _, _ in got) == [0, 1] and got[0][2] == got[1][2] > 150
