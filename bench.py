@@ -288,8 +288,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0                   # host time to ENQUEUE a step (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -334,7 +337,7 @@ def main():
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else "hipGraph replay", "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "grad_bytes": buckets.nbytes()},
+                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3), "grad_bytes": buckets.nbytes()},
             "roofline": roof, "cpu_baseline": cpu,
         }
         # value = whole-job throughput: every rank runs one B-sample step per step time (weak scaling) => world / t steps/s

@@ -140,5 +140,6 @@ def call(name: str, *args):
             conv.append(int(a))
     conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     rc = fn(*conv)
-    if rc != 0:
+    if rc < 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+    return rc                                  # > 0: "not applicable, nothing launched" (entry points that document it)

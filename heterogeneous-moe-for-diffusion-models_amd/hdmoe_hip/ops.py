@@ -91,8 +91,7 @@ _spacer = None
 
 def _timed(kind: str, info: dict, name: str, *args):
     if PROFILE is None:
-        call(name, *args)
-        return
+        return call(name, *args)
     # An event pair also spans the time the stream sits idle waiting for the host to enqueue the kernel.  A spacer launch in
     # front keeps the GPU busy while start event, kernel and end event are all enqueued, so the pair brackets the kernel alone.
     global _spacer
@@ -101,9 +100,11 @@ def _timed(kind: str, info: dict, name: str, *args):
     _spacer.zero_()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    call(name, *args)
+    rc = call(name, *args)
     e.record()
-    PROFILE.append((kind, info, s, e))
+    if rc == 0:
+        PROFILE.append((kind, dict(info, wgrad_name="wgrad6_kernel (+ reduce)") if name == "hdmoe_conv_wgrad6" else info, s, e))
+    return rc
 
 
 def _conv6_domain(x, Ho, Wo, O, I, Cstore, khs, kws, cphys, split):
@@ -176,6 +177,27 @@ def _kernel_hw(w: Tensor):
     if w.ndim == 2:
         return 1, 1
     raise ValueError(f"weight must be 2-D or 4-D, got {tuple(w.shape)}")
+
+
+_w6_ws = {}
+
+
+def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts):
+    """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers take the atomic-free
+    kernel (csrc/wgrad6.hip) with a cached workspace; everything else the general kernel."""
+    if x.dtype == torch.bfloat16 and not ones and Ho == H and Wo == W and Cphys == I:
+        from ._lib import lib, _int_array
+        import ctypes
+        kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
+                                             ctypes.cast(_int_array(kws), ctypes.c_void_p), _dt(x))
+        if kib > 0:
+            ws = _w6_ws.get(x.device)
+            if ws is None or ws.numel() < kib * 256:
+                ws = torch.empty(kib * 256, dtype=torch.float32, device=x.device)      # fp32 words; grown outside graph capture (warm-up steps)
+                _w6_ws[x.device] = ws
+            if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, _dt(x)) == 0:
+                return
+    _timed("conv_wgrad", info, "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
 
 
 class _MPConvFn(torch.autograd.Function):
@@ -258,8 +280,7 @@ class _MPConvFn(torch.autograd.Function):
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w and ctx.ent is not None:
             # bank path: accumulate into the bank's slab; one multi-tensor launch at the end of backward finishes every gradient
-            _timed("conv_wgrad", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_wgrad", x, dy, ctx.ent.G, seg, G, N, H, W,
-                   Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
+            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts)
             ctx.bank.note_backward(ctx.ent)
         elif need_w:
             sizes = [khs[g] * kws[g] * O * I for g in range(G)]
@@ -268,8 +289,7 @@ class _MPConvFn(torch.autograd.Function):
             for g in range(G):
                 Gs.append(Gflat[off:off + sizes[g]])
                 off += sizes[g]
-            _timed("conv_wgrad", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W,
-                   Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
+            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts)
             dws = [torch.empty_like(w) for w in weights]
             if need_gain:
                 dgs = [torch.zeros((), dtype=torch.float32, device=x.device) for _ in range(G)]

@@ -66,6 +66,14 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
                      int Ho, int Wo, int Cin, int Cphys, int Cout, int stride, int ones, const int* kh, const int* kw,
                      const int* pt, const int* pl, int dtype, HS stream);
 
+/* Atomic-free weight gradient for the k x k (k = 3, 5) bf16 layers (csrc/wgrad6.hip): same contract as hdmoe_conv_wgrad plus a
+ * caller-provided workspace of hdmoe_conv_wgrad6_ws_kib(...) KiB (0 = shape outside the kernel's domain).  hdmoe_conv_wgrad6
+ * returns 1 without launching when it does not apply; the caller then uses hdmoe_conv_wgrad. */
+int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, int dtype);
+int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin,
+                      int Cout, const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, int dtype,
+                      HS stream);
+
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
  * (tag << 56 | s_memtime) of every later launch; NULL switches it off (tools/conv6_check.py --stamps). */
 int hdmoe_conv6_debug_stamps(void* buf);

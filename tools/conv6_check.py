@@ -45,7 +45,7 @@ def check(N, R, Cin, Cout, ks, split, with_res, seed=0):
     go = torch.randn(N, R, R, Cout, generator=g).bfloat16()
     y.backward(go.to(dev))
     xr = x.float().requires_grad_(True)
-    wr = [w.float() for w in ws]
+    wr = [w.float().requires_grad_(True) for w in ws]
     outs = []
     for gi, w in enumerate(wr):
         xs = xr[seg[gi]:seg[gi + 1]].permute(0, 3, 1, 2)
@@ -53,8 +53,14 @@ def check(N, R, Cin, Cout, ks, split, with_res, seed=0):
         outs.append(F.conv2d(F.pad(xs, (pl, k - 1 - pl, pl, k - 1 - pl)), w).permute(0, 2, 3, 1))
     (alpha * torch.cat(outs, 0) * go.float()).sum().backward()
     gerr = float((xd.grad.float().cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max())
-    ok = err < 2e-2 and gerr < 2e-2
-    print(f"{'ok ' if ok else 'BAD'} N={N} R={R} {Cin}->{Cout} ks={ks} split={split} res={with_res}: fwd {err:.2e} dgrad {gerr:.2e}", flush=True)
+    werr = 0.0
+    for gi in range(len(ks)):
+        if seg[gi + 1] > seg[gi]:
+            werr = max(werr, float((wd[gi].grad.cpu() - wr[gi].grad).abs().max()) / float(wr[gi].grad.abs().max()))
+        else:
+            werr = max(werr, float(wd[gi].grad.abs().max()))
+    ok = err < 2e-2 and gerr < 2e-2 and werr < 2e-2
+    print(f"{'ok ' if ok else 'BAD'} N={N} R={R} {Cin}->{Cout} ks={ks} split={split} res={with_res}: fwd {err:.2e} dgrad {gerr:.2e} wgrad {werr:.2e}", flush=True)
     return ok
 
 
@@ -149,6 +155,38 @@ def timeit(N, R, Cin, Cout, ks, iters=20):
     print(f"time N={N} R={R} {Cin}->{Cout} ks={ks}: {us:8.1f} us  {flops / us / 1e6:7.1f} TF/s  {byts / us / 1e3:7.1f} GB/s", flush=True)
 
 
+def time_wgrad(N, R, Cin, Cout, ks, iters=10):
+    """Kernel time of the weight gradient (graph replay): wgrad6 + reduce vs the general kernel (HDMOE_WGRAD6=0 in another process)."""
+    from hdmoe_hip._lib import call
+    x = torch.randn(N, R, R, Cin, device=dev).bfloat16()
+    dy = torch.randn(N, R, R, Cout, device=dev).bfloat16()
+    E = len(ks)
+    seg = torch.tensor([N * i // E for i in range(E + 1)], dtype=torch.int32, device=dev)
+    Gs = [torch.zeros(k * k, Cout, Cin, device=dev) for k in ks]
+    pts = [(k - 1) // 2 for k in ks]
+    info = dict()
+    def run():
+        ops._wgrad(info, x, dy, Gs, seg, E, N, R, R, R, R, Cin, Cin, Cout, False, list(ks), list(ks), pts)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(iters):
+            run()
+    gr.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); gr.replay(); e.record(); torch.cuda.synchronize()
+    us = 1e3 * s.elapsed_time(e) / iters
+    fl = sum(2.0 * (N // E) * R * R * Cout * Cin * k * k for k in ks)
+    print(f"time wgrad N={N} R={R} {Cin}->{Cout} ks={ks}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+
+
 def stamps(N, R, Cin, Cout, ks):
     """One launch with in-kernel stamps of workgroup 0: per wave, (tag, cycles since the first stamp)."""
     import ctypes
@@ -189,6 +227,11 @@ def stamps(N, R, Cin, Cout, ks):
 
 if __name__ == "__main__":
     hdmoe_hip.lib()
+    if "--wgrad" in sys.argv:
+        for (N, R, Ci, Co) in [(512, 32, 32, 32), (512, 16, 64, 64), (512, 32, 64, 64), (512, 32, 96, 32), (512, 16, 128, 64)]:
+            time_wgrad(N, R, Ci, Co, [3, 3, 5, 5])
+        time_wgrad(512, 16, 64, 64, [5]); time_wgrad(512, 16, 64, 64, [3]); time_wgrad(512, 32, 32, 32, [5])
+        sys.exit(0)
     if "--split" in sys.argv:
         good = True
         good &= check_split(3, 32, 32, 64)
