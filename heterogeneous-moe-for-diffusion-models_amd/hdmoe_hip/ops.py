@@ -181,6 +181,18 @@ def _kernel_hw(w: Tensor):
 
 _w6_ws = {}
 
+# Small learnable tensors (norm affines, biases, rel_pos_bias, alpha_txt): when the parameter already owns a gradient buffer (the
+# flat DP buckets, or a .grad kept from the previous step) the backward kernels -- which accumulate anyway -- add straight into it
+# and hand autograd None.  That is what the weight bank does for the conv weights; per step it removes a zero-fill and an
+# AccumulateGrad add per parameter (~300 launches of ~5 us that the host enqueues one by one).  HDMOE_DIRECT_PARAM_GRADS=0: off.
+DIRECT_PARAM_GRADS = _os.environ.get("HDMOE_DIRECT_PARAM_GRADS", "1") != "0"
+
+
+def _direct(p) -> bool:
+    return (DIRECT_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
+            and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.shape == p.shape)
+
+
 
 def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts):
     """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers take the atomic-free
@@ -754,6 +766,7 @@ class _BiasAddFn(torch.autograd.Function):
         out = torch.empty_like(x)
         call("hdmoe_bias_add", out, x, bias, x.numel() // L, L, _dt(x))
         ctx.bshape = bias.shape
+        ctx.bias_param = bias if (bias.is_leaf and bias.requires_grad) else None
         return out
 
     @staticmethod
@@ -764,8 +777,12 @@ class _BiasAddFn(torch.autograd.Function):
             L = 1
             for d in ctx.bshape:
                 L *= d
-            db = torch.zeros(ctx.bshape, dtype=torch.float32, device=g.device)
-            call("hdmoe_colsum", db, g, g.numel() // L, L, _dt(g))
+            bp = ctx.bias_param
+            if _direct(bp):
+                call("hdmoe_colsum", bp.grad, g, g.numel() // L, L, _dt(g))
+            else:
+                db = torch.zeros(ctx.bshape, dtype=torch.float32, device=g.device)
+                call("hdmoe_colsum", db, g, g.numel() // L, L, _dt(g))
         return g, db
 
 
@@ -788,9 +805,10 @@ class _LerpParamFn(torch.autograd.Function):
         a, b, alpha = ctx.saved_tensors
         g = _c(g)
         da, db = torch.empty_like(a), torch.empty_like(b)
-        dal = torch.zeros_like(alpha)
+        direct = _direct(alpha)
+        dal = alpha.grad if direct else torch.zeros_like(alpha)
         call("hdmoe_lerp_param_bwd", da, db, dal, g, a, b, alpha, a.numel(), _dt(a))
-        return da, db, dal
+        return da, db, (None if direct else dal)
 
 
 def lerp_param(a: Tensor, b: Tensor, alpha: Tensor) -> Tensor:
@@ -1099,8 +1117,9 @@ class _GroupNormFn(torch.autograd.Function):
         N, S, C, G, act = ctx.meta
         g = _c(g)
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(beta)
+        direct = _direct(gamma) and _direct(beta)
+        dgamma = gamma.grad if direct else torch.zeros_like(gamma)
+        dbeta = beta.grad if direct else torch.zeros_like(beta)
         parts = _gn_parts(N, S, forward=False)
         if parts > 1:
             ws = torch.zeros(2 * N * G, dtype=torch.float32, device=x.device)
@@ -1108,6 +1127,8 @@ class _GroupNormFn(torch.autograd.Function):
         else:
             ws = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
             call("hdmoe_groupnorm_bwd", dx, dgamma, dbeta, ws, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
+        if direct:
+            return dx, None, None, None, None, None
         return dx, dgamma, dbeta, None, None, None
 
 
@@ -1140,18 +1161,21 @@ class _LayerNormFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         y = torch.empty_like(x)
         call("hdmoe_layernorm_fwd", y, mean, rstd, x, gamma, beta, rows, C, eps, _dt(x))
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, gamma, mean, rstd, beta)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, gamma, mean, rstd, beta = ctx.saved_tensors
         g = _c(g)
         C = x.shape[-1]
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
+        direct = _direct(gamma) and _direct(beta)
+        dgamma = gamma.grad if direct else torch.zeros_like(gamma)
+        dbeta = beta.grad if direct else torch.zeros_like(gamma)
         call("hdmoe_layernorm_bwd", dx, dgamma, dbeta, g, x, gamma, mean, rstd, x.numel() // C, C, _dt(x))
+        if direct:
+            return dx, None, None, None
         return dx, dgamma, dbeta, None
 
 
@@ -1191,12 +1215,14 @@ class _AttnFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         dbias = None
         Sb = 0
+        direct = False
         if bias is not None:
             Sb = bias.shape[-1]
             if ctx.needs_input_grad[3]:
-                dbias = torch.zeros_like(bias)
+                direct = _direct(bias)
+                dbias = bias.grad if direct else torch.zeros_like(bias)
         call("hdmoe_attn_bwd", dq, dk, dv, dbias, delta, g, out, q, k, v, lse, bias, B, Sq, Skv, H, E // H, Sb, _dt(q))
-        return dq, dk, dv, dbias, None
+        return dq, dk, dv, (None if direct else dbias), None
 
 
 class _BicubicFn(torch.autograd.Function):
