@@ -82,6 +82,7 @@ def pmc_traffic(kernel_name):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None
+    pmc_traffic.source = os.path.join("profiles", os.path.basename(files[-1]))
     tbl = json.load(open(files[-1]))
     keys = [kernel_name]
     m = re.match(r"(\w+)<__bf16, (.*)>", kernel_name)
@@ -133,21 +134,41 @@ def roofline_leg(step_fn, n_steps):
             a["n"] += 1
     if not agg:
         return None, {}
+    def roof_of(name, a):
+        peak = MFMA_PEAK[a["dtype"]]
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        tr = pmc_traffic(name)
+        return dict(bound="mfma", kernel=name, dtype=a["dtype"], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                    traffic=tr, traffic_source=getattr(pmc_traffic, "source", None) if tr is not None else None,
+                    avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps, ms_per_step=round(a["ms"] / n_steps, 3))
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    # the expert grouped-GEMM kernels (bf16): the north_star's MFMA-utilisation target is about these, whatever kernel dominates
+    bf = {k: v for k, v in agg.items() if v["dtype"] == "bfloat16" and ("conv6" in k or "wgrad6" in k)}
+    expert = None
+    if bf:
+        en, ea = max(bf.items(), key=lambda kv: kv[1]["ms"])
+        expert = roof_of(en, ea)
+        tot_ms = sum(v["ms"] for v in bf.values()); tot_fl = sum(v["flops"] for v in bf.values())
+        expert["all_expert_kxk_kernels"] = dict(ms_per_step=round(tot_ms / n_steps, 3), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                                frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK["bfloat16"], 4),
+                                                note="time-weighted over conv6 (fwd+dgrad) and wgrad6 launches, realised routing")
+    roofline_leg.expert = expert
     peak = MFMA_PEAK[a["dtype"]]
     ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
     table = {k: dict(launches_per_step=v["n"] / n_steps, avg_us=1e3 * v["ms"] / v["n"], ms_per_step=v["ms"] / n_steps,
                      tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in agg.items()}
     table["_by_shape_ms_per_step"] = {k: [round(v[0] / n_steps, 3), v[1] / n_steps]
                                       for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:25]}
-    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                traffic=pmc_traffic(name), avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps,
+    tr = pmc_traffic(name)
+    return dict(bound="mfma", kernel=name, dtype=a["dtype"], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                traffic=tr, traffic_source=getattr(pmc_traffic, "source", None) if tr is not None else None,
+                avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps, ms_per_step=round(a["ms"] / n_steps, 3),
                 method="HIP events around each launch on the launch stream, a spacer launch in front keeps host enqueue gaps out and the event-pair overhead measured on a trivial launch is subtracted; see profiles/", event_overhead_us=round(1e3 * overhead, 2)), table
 
 
 def cpu_baseline(cfg_id, kw, module, seconds=12.0):
     """The CPU oracle (port of the reference algorithm) timed on the host cores on a bounded sample: B = 8 samples per
-    step, eval-mode fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
+    step, TRAIN-mode (dropout 0.2, logit noise zeta 0.1) fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
     from oracle import hdmoe_oracle as O
     import configs as C
     from models import model_config1, model_config2
@@ -174,6 +195,7 @@ def cpu_baseline(cfg_id, kw, module, seconds=12.0):
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
     lc = C.loss_configs
+    O.TRAIN.update(on=True, p=0.2, zeta=0.1)                 # the GPU step runs in train mode: so does the baseline
     times = []
     t_end = time.time() + seconds
     while time.time() < t_end or len(times) < 2:
@@ -188,6 +210,7 @@ def cpu_baseline(cfg_id, kw, module, seconds=12.0):
         print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
         if len(times) >= 40:
             break
+    O.TRAIN.update(on=False)
     med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
     return med, B, cores, len(times)
 
@@ -307,6 +330,31 @@ def main():
     gc.enable()
     loss_val = float(loss["loss"].detach())
 
+    # second leg: the same step with MaskGenerator(step=0, BW=0.3) masks instead of all-ones -- routing restricted to
+    # each sample's noise band.  The masks are graph inputs: copied into the captured tensors, no re-capture.
+    ms_masked = None
+    try:
+        mc = C.mask_configs
+        sig = inp["sigma"].flatten()
+        mg_u = U.MaskGenerator(expert_attributes=[k[0] for k in kw["Unet_kernel_sizes"]], p_mean=mc["p_mean"], p_std=mc["p_std"], bandwidth=mc["BW"],
+                               max_bandwidth=mc["max_BW"], min_active=mc["min_active"], step_size=mc["step_size"],
+                               noise_range=mc["unet_noise_range"], strat_band=mc["strat_band"])
+        mg_v = U.MaskGenerator(expert_attributes=list(kw["VIT_patch_sizes"]), p_mean=mc["p_mean"], p_std=mc["p_std"], bandwidth=mc["BW"],
+                               max_bandwidth=mc["max_BW"], min_active=mc["min_active"], step_size=mc["step_size"],
+                               noise_range=mc["vit_noise_range"], strat_band=mc["strat_band"])
+        um_save, vm_save = inp["um"].clone(), inp["vm"].clone()
+        inp["um"].copy_(mg_u(sig, 0).to(device)); inp["vm"].copy_(mg_v(sig, 0).to(device))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ms_masked = 1e3 * (time.perf_counter() - tm) / args.steps
+        inp["um"].copy_(um_save); inp["vm"].copy_(vm_save)
+    except Exception as exc:                                  # diagnostic leg only
+        print(f"[bench] masked leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
     roof, table = (None, {})
     cpu = None
     if rank == 0:
@@ -319,7 +367,7 @@ def main():
             med, cb, cores, nst = cpu_baseline(args.config, kw, bc["module"])
             # metric unit: steps of B samples per second -> a CPU step of cb samples counts as cb/B of a bench step
             cpu = dict(value=round((cb / med) / B, 5), unit="denoise-steps/sec", cores=cores, kind="port",
-                       sample=f"CPU oracle, fp32, eval-mode fwd+loss+bwd on B={cb} samples/step, median of {nst - 1} steps "
+                       sample=f"CPU oracle, fp32, train-mode (dropout, logit noise) fwd+loss+bwd on B={cb} samples/step, {cores} threads, median of {nst - 1} steps "
                               f"({med:.2f} s/step = {cb / med:.2f} samples/s), scaled to the bench's {B}-sample step")
     if world > 1:
         dist.barrier()
@@ -337,8 +385,10 @@ def main():
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else "hipGraph replay", "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3), "grad_bytes": buckets.nbytes()},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
+                       "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
+                                + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
+            "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "cpu_baseline": cpu,
         }
         # value = whole-job throughput: every rank runs one B-sample step per step time (weak scaling) => world / t steps/s
         print(json.dumps(line), flush=True)

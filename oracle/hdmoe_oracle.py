@@ -34,6 +34,20 @@ Params = Dict[str, Tensor]
 
 MP_SILU_DIV = 0.596
 
+# Train-mode switch for the timed CPU baseline (bench.py): dropout p = 0.2 in every Unet_block (model_components.py:245-246), in
+# the router trunks (:111) and in Scaling_router (:37), logit noise randn * zeta (:61-62, :155-156).  Parity tests run with it off
+# (torch's CPU RNG stream cannot be matched by the device RNG); the in-place weight renormalisation (model_internals.py:254-256) is
+# a no-op on the value of the forward and is not re-stated.
+TRAIN = {"on": False, "p": 0.2, "zeta": 0.0}
+
+
+def _drop(x: Tensor) -> Tensor:
+    return F.dropout(x, TRAIN["p"], training=True) if TRAIN["on"] else x
+
+
+def _noise(x: Tensor) -> Tensor:
+    return x + torch.randn_like(x) * TRAIN["zeta"] if TRAIN["on"] and TRAIN["zeta"] else x
+
 
 # --------------------------------------------------------------------------
 # L0: magnitude-preserving primitives            models/model_internals.py
@@ -178,8 +192,8 @@ def scaling_router(P: Params, pre: str, x: Tensor, logit_noise: Optional[Tensor]
     if x.ndim == 3:
         x = x.squeeze(1)
     x = F.relu(group_norm(P, pre + "soft_route.1.", mp_conv(x, P[pre + "soft_route.0.weights"]), 1))
-    x = F.relu(group_norm(P, pre + "soft_route.4.", mp_conv(x, P[pre + "soft_route.3.weights"]), 1))
-    x = mp_conv(x, P[pre + "linear.weights"])
+    x = _drop(F.relu(group_norm(P, pre + "soft_route.4.", mp_conv(x, P[pre + "soft_route.3.weights"]), 1)))
+    x = _noise(mp_conv(x, P[pre + "linear.weights"]))
     if logit_noise is not None:
         x = x + logit_noise
     return F.softmax(x, dim=-1) * 2.0
@@ -203,7 +217,7 @@ def router_logits(P: Params, pre: str, x: Tensor, time_emb: Tensor) -> Tensor:
     for conv_i, gn_i in ((0, 1), (3, 4), (6, 7)):
         x = mp_conv(x, P[f"{pre}hard_route.{conv_i}.weights"])
         x = F.relu(group_norm(P, f"{pre}hard_route.{gn_i}.", x, 1))
-    x = x.mean(dim=(2, 3)).reshape(B, -1)
+    x = _drop(x.mean(dim=(2, 3)).reshape(B, -1))
     if time_emb.ndim == 3:
         time_emb = time_emb.squeeze(1)
     cond = mp_conv(mp_silu(time_emb), P[pre + "time_linear.weights"])
@@ -216,7 +230,7 @@ def router(P: Params, pre: str, x: Tensor, time_emb: Tensor, mask: Optional[Tens
            logit_noise: Optional[Tensor] = None):
     """Router.forward (model_components.py:118-168).  ``logit_noise`` stands in
     for the train-mode ``randn*zeta`` draw so it can be supplied explicitly."""
-    logits = router_logits(P, pre, x, time_emb)
+    logits = _noise(router_logits(P, pre, x, time_emb))
     if logit_noise is not None:
         logits = logits + logit_noise
     sparse, probs, logits, _ = router_head(logits, mask, k)
@@ -234,7 +248,7 @@ def unet_block(P: Params, pre: str, x: Tensor, emb: Tensor, kind: str, mode: str
             x = mp_conv(x, P[pre + "conv_skip.weights"])
         x = normalize(x, dim=[1])
     y = mp_conv(mp_silu(x), P[pre + "conv_res1.weights"])
-    y = mp_silu(y * e[:, :, None, None].to(x.dtype))
+    y = _drop(mp_silu(y * e[:, :, None, None].to(x.dtype)))
     y = mp_conv(y, P[pre + "conv_res2.weights"])
     if kind == "dec" and has_skip:
         x = mp_conv(x, P[pre + "conv_skip.weights"])
