@@ -37,7 +37,10 @@ struct W6Args {
   long ws_item;                       // floats of one partial slab (taps * Cout * Cin)
 };
 
-template <int KS, int TWS, int OT>
+// SPLIT: x and dy are fp32 (the router trunks); every operand is split into hi + lo bf16 while it is staged (through registers) and
+// a product is three MFMAs, dy_hi x_hi + dy_hi x_lo + dy_lo x_hi -- see conv6s.hip.  LDS then holds a hi and a lo plane of each
+// tile (single-buffered: the next tile waits in registers, loaded beside the current tile's loop).
+template <int KS, int TWS, int OT, bool SPLIT>
 __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TW = 1 << TWS, TH = 256 >> TWS, HWp = TW + KS - 1, HHp = TH + KS - 1, NTAPS = KS * KS;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
   constexpr int DYROW = 64 * OT;                            // bytes per dy pixel row in LDS
   constexpr int NFULL = NTAPS / 8, REM = NTAPS % 8;         // full taps per wave / taps left over
   static_assert(REM * OT <= 8, "left-over tiles must fit one per wave");
-  constexpr int XBUF = HP16 * 1024, DYBUF = DYP * 1024, BUF = XBUF + DYBUF;
+  constexpr int XBUF = HP16 * 1024, DYBUF = DYP * 1024, BUF = XBUF + DYBUF;   // SPLIT: buffer 0 = hi planes, buffer 1 = lo planes
   constexpr int NXP = (HP16 + 7) / 8, NDP = DYP / 8;        // DMA pieces per wave
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -68,6 +71,56 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
   const int u0 = chunk * a.upw, u1 = min(units, u0 + a.upw);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dybytes, 0x00020000);
+  // ---- SPLIT staging: 16-byte pieces = 4 fp32 channels of one pixel; thread t handles pieces t, t + 512, ..
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  constexpr int XQ = 8, DYQ = 8 * OT;                        // pieces per pixel (32 / 32*OT channels)
+  constexpr int NXS = (HP16 * 16 * XQ + 511) / 512, NDS = 256 * DYQ / 512;
+  f4 sxr[SPLIT ? NXS : 1], sdr[SPLIT ? NDS : 1];
+  auto split_load = [&](int n, int ty0, int tx0) {
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+      const int e = tid + 512 * k;
+      const int px = e / XQ, cqx = e - px * XQ;
+      const int hy = px / HWp, hx = px - hy * HWp;
+      const int iy = ty0 - a.pt + hy, ix = tx0 - a.pl + hx;
+      const bool ok = px < HWp * HHp && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + i0) * 4 + cqx * 16) : 0xFFFFFFFFu;
+      sxr[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NDS; ++k) {
+      const int e = tid + 512 * k;
+      const int q = e / DYQ, cqd = e - q * DYQ;
+      const int oy = ty0 + (q >> TWS), ox = tx0 + (q & (TW - 1));
+      const bool ok = oy < a.H && ox < a.W;
+      const unsigned off = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + o0) * 4 + cqd * 16) : 0xFFFFFFFFu;
+      sdr[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+    }
+  };
+  auto split_store = [&]() {                                  // registers -> hi / lo bf16 planes (same images as the DMA path)
+    auto put = [&](const f4& v, int off) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+      *reinterpret_cast<bf16x4*>(lds + off) = hi;
+      *reinterpret_cast<bf16x4*>(lds + BUF + off) = lo;
+    };
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+      const int e = tid + 512 * k;
+      const int px = e / XQ, cqx = e - px * XQ;
+      if (px < HP16 * 16) put(sxr[k], px * 64 + cqx * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NDS; ++k) {
+      const int e = tid + 512 * k;
+      const int q = e / DYQ, c0 = 4 * (e - q * DYQ);
+      int off;
+      if (OT == 2) off = q * DYROW + ((((c0 >> 3) ^ (((q >> 1) & 1) << 2))) << 4) + ((c0 >> 2) & 1) * 8;
+      else off = q * DYROW + c0 * 2;
+      put(sdr[k], XBUF + off);
+    }
+  };
 
   // ---- DMA of one tile (unit u of this expert) into buffer `b`; piece k of this wave (k static at every call site)
   auto tile_origin = [&](int u, int& n, int& ty0, int& tx0) {
@@ -132,6 +185,50 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
     for (int t = 0; t < OT; ++t) acc[s][t] = (f32x16)(0.f);
   acce = (f32x16)(0.f);
 
+  if constexpr (SPLIT) {
+    {
+      int n, ty0, tx0;
+      tile_origin(u0, n, ty0, tx0);
+      split_load(n, ty0, tx0);
+      split_store();
+    }
+    for (int u = u0; u < u1; ++u) {
+      __syncthreads();                                        // tile u's planes are complete
+      const bool more = u + 1 < u1;
+      if (more) {                                             // next tile: fp32 registers, in flight beside the loop below
+        int nn, nty0, ntx0;
+        tile_origin(u + 1, nn, nty0, ntx0);
+        split_load(nn, nty0, ntx0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int krow = (16 * ks) >> TWS, kcol = (16 * ks) & (TW - 1);
+        const int kx_off = (krow * HWp + kcol) * 64;
+        const int kdy_off = 16 * ks * DYROW;
+        bf16x8 dh[OT], dl[OT], xh[NFULL + 1], xl[NFULL + 1];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) { dh[t] = tr2(XBUF + dylane[t] + kdy_off, 4 * DYROW); dl[t] = tr2(BUF + XBUF + dylane[t] + kdy_off, 4 * DYROW); }
+#pragma unroll
+        for (int s2 = 0; s2 <= NFULL; ++s2) { xh[s2] = tr2(xlane + tapoff[s2] + kx_off, 4 * 64); xl[s2] = tr2(BUF + xlane + tapoff[s2] + kx_off, 4 * 64); }
+#pragma unroll
+        for (int s2 = 0; s2 < NFULL; ++s2)
+#pragma unroll
+          for (int t = 0; t < OT; ++t) {
+            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xh[s2], acc[s2][t], 0, 0, 0);
+            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xl[s2], acc[s2][t], 0, 0, 0);
+            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[t], xh[s2], acc[s2][t], 0, 0, 0);
+          }
+        const bf16x8 deh = (OT == 2 && eob) ? dh[OT - 1] : dh[0], del = (OT == 2 && eob) ? dl[OT - 1] : dl[0];
+        acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(deh, xh[NFULL], acce, 0, 0, 0);
+        acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(deh, xl[NFULL], acce, 0, 0, 0);
+        acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(del, xh[NFULL], acce, 0, 0, 0);
+      }
+      if (more) {
+        __syncthreads();                                      // every wave is done reading tile u
+        split_store();
+      }
+    }
+  } else {
   // prologue: first tile into buffer 0
   {
     int n, ty0, tx0;
@@ -174,6 +271,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
       acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdye, fxe, acce, 0, 0, 0);
     }
     par ^= 1;
+  }
   }
   // ---- partial slab [tap][Cout][Cin] of this (expert, pixel partition): plain stores, 128-byte runs
   float* P = a.ws + (long)blockIdx.z * a.ws_item;
@@ -238,13 +336,13 @@ void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw
   upw = (int)u; slots = (int)(units_l / u + ngr);
 }
 
-template <int KS, int TWS, int OT>
+template <int KS, int TWS, int OT, bool SPLIT>
 void launch_w6(const W6Args& a, int ibs, int obs, hipStream_t stream) {
   constexpr int TW = 1 << TWS, TH = 256 >> TWS, HP16 = ((TW + KS - 1) * (TH + KS - 1) + 15) / 16;
-  const size_t lds = 2 * (size_t)(HP16 * 1024 + 16 * OT * 1024);
+  const size_t lds = 2 * (size_t)(HP16 * 1024 + 16 * OT * 1024);     // two DMA buffers, or (SPLIT) a hi and a lo plane
   static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)wgrad6_kernel<KS, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-  hipLaunchKernelGGL((wgrad6_kernel<KS, TWS, OT>), dim3(ibs, obs, a.chunks), dim3(512), lds, stream, a);
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)wgrad6_kernel<KS, TWS, OT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  hipLaunchKernelGGL((wgrad6_kernel<KS, TWS, OT, SPLIT>), dim3(ibs, obs, a.chunks), dim3(512), lds, stream, a);
 }
 
 }  // namespace
@@ -253,10 +351,10 @@ extern "C" {
 
 // Workspace KiB hdmoe_conv_wgrad6 needs for a launch of this shape (0: outside the kernel's domain, use hdmoe_conv_wgrad).
 int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, int dtype) {
-  if (dtype != HDMOE_BF16 || Cin % 32 || Cout % 32 || !(W == 16 || W % 32 == 0) || H < 8 || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return 0;
+  if ((dtype != HDMOE_BF16 && dtype != HDMOE_F32S) || Cin % 32 || Cout % 32 || !(W == 16 || W % 32 == 0) || H < 8 || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return 0;
   long maxtaps = 0;
   for (int g = 0; g < ngroups; ++g) {
-    if (kh[g] != kw[g] || (kh[g] != 3 && kh[g] != 5)) return 0;
+    if (kh[g] != kw[g] || (kh[g] != 3 && kh[g] != 5) || (dtype == HDMOE_F32S && kh[g] != 3)) return 0;
     if ((long)kh[g] * kw[g] > maxtaps) maxtaps = (long)kh[g] * kw[g];
   }
   const int TW = W >= 32 ? 32 : 16, TH = 256 / TW, OT = Cout % 64 == 0 ? 2 : 1;
@@ -286,7 +384,8 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
   if (need == 0 || !ws || ws_bytes < need || !x || !dy || !G) return 1;
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) return 1;
   for (int g = 0; g < ngroups; ++g) if (((uintptr_t)G[g] & 15) || pt[g] != (kh[g] - 1) / 2 || pl[g] != (kw[g] - 1) / 2) return 1;
-  const long xbytes = (long)N * H * W * Cin * 2, dybytes = (long)N * H * W * Cout * 2;
+  const int esz = dtype == HDMOE_F32S ? 4 : 2;
+  const long xbytes = (long)N * H * W * Cin * esz, dybytes = (long)N * H * W * Cout * esz;
   if (xbytes >= (1l << 31) || dybytes >= (1l << 31)) return 1;
   if (N == 0) return HDMOE_OK;
   const int TWS = W >= 32 ? 5 : 4, TW = 1 << TWS, TH = 256 / TW;
@@ -310,8 +409,11 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
     w6_partition(units_l, a.ngr, ngroups, ibs, obs, upw, slots);
     a.upw = upw; a.chunks = slots;                          // (chunks = partition slots of this class)
     const W6Args& b = a;                                    // (kernel-size classes reuse the workspace: each class's reduce runs before the next class)
-#define W6_LAUNCH(K, T, O) launch_w6<K, T, O>(b, ibs, obs, stream)
-    if (ks == 3) { if (TWS == 5) { if (OT == 2) W6_LAUNCH(3, 5, 2); else W6_LAUNCH(3, 5, 1); } else { if (OT == 2) W6_LAUNCH(3, 4, 2); else W6_LAUNCH(3, 4, 1); } }
+#define W6_LAUNCH(K, T, O) launch_w6<K, T, O, false>(b, ibs, obs, stream)
+    if (dtype == HDMOE_F32S) {
+      if (TWS == 5) { if (OT == 2) launch_w6<3, 5, 2, true>(b, ibs, obs, stream); else launch_w6<3, 5, 1, true>(b, ibs, obs, stream); }
+      else { if (OT == 2) launch_w6<3, 4, 2, true>(b, ibs, obs, stream); else launch_w6<3, 4, 1, true>(b, ibs, obs, stream); }
+    } else if (ks == 3) { if (TWS == 5) { if (OT == 2) W6_LAUNCH(3, 5, 2); else W6_LAUNCH(3, 5, 1); } else { if (OT == 2) W6_LAUNCH(3, 4, 2); else W6_LAUNCH(3, 4, 1); } }
     else { if (TWS == 5) { if (OT == 2) W6_LAUNCH(5, 5, 2); else W6_LAUNCH(5, 5, 1); } else { if (OT == 2) W6_LAUNCH(5, 4, 2); else W6_LAUNCH(5, 4, 1); } }
     W6Ptrs gp;
     for (int k = 0; k < HDMOE_MAX_GROUPS; ++k) gp.G[k] = k < b.ngr ? G[b.groups[k]] : nullptr;

@@ -103,7 +103,9 @@ def _timed(kind: str, info: dict, name: str, *args):
     rc = call(name, *args)
     e.record()
     if rc == 0:
-        PROFILE.append((kind, dict(info, wgrad_name="wgrad6_kernel (+ reduce)") if name == "hdmoe_conv_wgrad6" else info, s, e))
+        if name == "hdmoe_conv_wgrad6":
+            info = dict(info, wgrad_name="wgrad6_kernel<split> (+ reduce)" if info.get("dtype") == "split_bf16" else "wgrad6_kernel (+ reduce)")
+        PROFILE.append((kind, info, s, e))
     return rc
 
 
@@ -194,20 +196,24 @@ def _direct(p) -> bool:
 
 
 
-def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts):
-    """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers take the atomic-free
-    kernel (csrc/wgrad6.hip) with a cached workspace; everything else the general kernel."""
-    if x.dtype == torch.bfloat16 and not ones and Ho == H and Wo == W and Cphys == I:
+def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split=False):
+    """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers -- and fp32 layers in
+    split-bf16 mode (the router trunks) -- take the atomic-free kernel (csrc/wgrad6.hip) with a cached workspace; everything else
+    the general kernel."""
+    if (x.dtype == torch.bfloat16 or split) and not ones and Ho == H and Wo == W and Cphys == I:
         from ._lib import lib, _int_array
         import ctypes
+        dtc = F32S if split else _dt(x)
         kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
-                                             ctypes.cast(_int_array(kws), ctypes.c_void_p), _dt(x))
+                                             ctypes.cast(_int_array(kws), ctypes.c_void_p), dtc)
         if kib > 0:
             ws = _w6_ws.get(x.device)
             if ws is None or ws.numel() < kib * 256:
                 ws = torch.empty(kib * 256, dtype=torch.float32, device=x.device)      # fp32 words; grown outside graph capture (warm-up steps)
                 _w6_ws[x.device] = ws
-            if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, _dt(x)) == 0:
+            if split:
+                info = dict(info, dtype="split_bf16")
+            if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc) == 0:
                 return
     _timed("conv_wgrad", info, "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
 
@@ -292,7 +298,7 @@ class _MPConvFn(torch.autograd.Function):
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w and ctx.ent is not None:
             # bank path: accumulate into the bank's slab; one multi-tensor launch at the end of backward finishes every gradient
-            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts)
+            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split)
             ctx.bank.note_backward(ctx.ent)
         elif need_w:
             sizes = [khs[g] * kws[g] * O * I for g in range(G)]
@@ -301,7 +307,7 @@ class _MPConvFn(torch.autograd.Function):
             for g in range(G):
                 Gs.append(Gflat[off:off + sizes[g]])
                 off += sizes[g]
-            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts)
+            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split)
             dws = [torch.empty_like(w) for w in weights]
             if need_gain:
                 dgs = [torch.zeros((), dtype=torch.float32, device=x.device) for _ in range(G)]

@@ -460,7 +460,7 @@ def test_mp_conv_vs_oracle(dtype, rel, cin, cout, k, hw):
 def test_split_bf16_conv_vs_fp64(cin, cout, hw, n):
     """Router-trunk convs in bf16 compute mode: fp32 tensors on the bf16 matrix pipe as split bf16 (hi + lo, three MFMAs per product,
     csrc/conv6s.hip).  Against an fp64 CPU conv the error is ~5e-6 of the tensor's max (fp32 MFMA: ~1e-7; plain bf16: ~4e-3) for the
-    forward and dgrad; wgrad stays on the fp32 kernel."""
+    forward, dgrad and wgrad (csrc/wgrad6.hip, SPLIT)."""
     import torch.nn.functional as F
     from hdmoe_hip import ops
     g = torch.Generator().manual_seed(cin + cout)
@@ -477,7 +477,7 @@ def test_split_bf16_conv_vs_fp64(cin, cout, hw, n):
     (y64 * go.double()).sum().backward()
     close_scaled(y, y64.float(), 2e-5, msg="split fwd")
     close_scaled(xd.grad, x64.grad.float(), 2e-5, msg="split dgrad")
-    close_scaled(wd.grad, w64.grad.float(), 1e-5, msg="wgrad (fp32 kernel)")
+    close_scaled(wd.grad, w64.grad.float(), 2e-5, msg="split wgrad")
 
 
 @pytest.mark.parametrize("rows", [2045 * 128, 262144, 3000 * 128 + 64])
