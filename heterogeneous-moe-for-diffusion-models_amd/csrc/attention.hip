@@ -592,6 +592,206 @@ __global__ __launch_bounds__(256) void bicubic_kernel(float* dst, const float* s
   }
 }
 
+// =====================================================================================================================
+// Ragged self-attention of the ViT expert bank (see ragged.hip): rows [seg[g], seg[g+1]) of the padded [R][Sp][E] tensors belong to
+// expert g, hold len[g] real tokens and use that expert's rel_pos_bias table.  One 64-lane workgroup per (row, head): the head's
+// K / V (and in the backward Q / dO) rows sit in LDS as fp32, thread = query row (forward, dq) or key row (dk, dv).  Padding
+// tokens get zero outputs and zero gradients.
+struct RagA {
+  const int* seg; int ng;
+  int len[HDMOE_MAX_GROUPS], sb[HDMOE_MAX_GROUPS];
+  const float* bias[HDMOE_MAX_GROUPS];
+  float* dbias[HDMOE_MAX_GROUPS];
+  long off[HDMOE_MAX_GROUPS + 1];                           // dbias walker: first thread of each expert
+};
+DEVI int raga_group(const RagA& r, int row) {
+  int g = -1;
+  for (int i = 0; i < r.ng; ++i)
+    if (row >= r.seg[i] && row < r.seg[i + 1]) g = i;
+  return g;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void attn_rag_fwd_kernel(T* out, float* lse, const T* q, const T* k, const T* v, RagA rg, int Sp, int H,
+                                                         float scale) {
+  extern __shared__ float sm_rag[];
+  const int r = blockIdx.x, h = blockIdx.y, E = H * D;
+  const int g = raga_group(rg, r);
+  const int len = g >= 0 ? rg.len[g] : 0;
+  float* sk = sm_rag;
+  float* sv = sm_rag + len * D;
+  for (int e = threadIdx.x; e < len * D; e += 64) {
+    const long src = ((long)r * Sp + e / D) * E + h * D + e % D;
+    sk[e] = to_f(k[src]); sv[e] = to_f(v[src]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Sp; i += 64) {
+    const long row = ((long)r * Sp + i) * E + h * D;
+    if (i >= len) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) out[row + d] = from_f<T>(0.f);
+      lse[((long)r * H + h) * Sp + i] = 0.f;
+      continue;
+    }
+    float qv[D], o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = to_f(q[row + d]) * scale; o[d] = 0.f; }
+    const float* brow = rg.bias[g] + ((long)h * rg.sb[g] + i) * rg.sb[g];
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < len; ++j) {
+      float a = brow[j];
+#pragma unroll
+      for (int d = 0; d < D; ++d) a += qv[d] * sk[j * D + d];
+      const float mn = fmaxf(m, a);
+      const float corr = __expf(m - mn), p = __expf(a - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] = o[d] * corr + p * sv[j * D + d];
+      m = mn;
+    }
+    const float il = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[row + d] = from_f<T>(o[d] * il);
+    lse[((long)r * H + h) * Sp + i] = m + __logf(l);
+  }
+}
+
+// dq, dk, dv (and delta for the dbias walker) of one (row, head)
+template <typename T, int D>
+__global__ __launch_bounds__(64) void attn_rag_bwd_kernel(T* dq, T* dk, T* dv, float* delta, const T* dout, const T* out, const T* q,
+                                                         const T* k, const T* v, const float* lse, RagA rg, int Sp, int H, float scale) {
+  extern __shared__ float sm_rag[];
+  const int r = blockIdx.x, h = blockIdx.y, E = H * D;
+  const int g = raga_group(rg, r);
+  const int len = g >= 0 ? rg.len[g] : 0;
+  float* sq = sm_rag;                                        // q * scale
+  float* sk = sq + len * D;
+  float* sv = sk + len * D;
+  float* sdo = sv + len * D;
+  float* sl = sdo + len * D;                                 // lse
+  float* sd = sl + len;                                      // delta
+  for (int e = threadIdx.x; e < len * D; e += 64) {
+    const long src = ((long)r * Sp + e / D) * E + h * D + e % D;
+    sq[e] = to_f(q[src]) * scale; sk[e] = to_f(k[src]); sv[e] = to_f(v[src]); sdo[e] = to_f(dout[src]);
+  }
+  for (int i = threadIdx.x; i < len; i += 64) {
+    const long row = ((long)r * Sp + i) * E + h * D;
+    float dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dl += to_f(dout[row + d]) * to_f(out[row + d]);
+    sd[i] = dl; sl[i] = lse[((long)r * H + h) * Sp + i];
+    delta[((long)r * H + h) * Sp + i] = dl;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Sp; i += 64) {               // thread = query row: dq
+    const long row = ((long)r * Sp + i) * E + h * D;
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    if (i < len) {
+      const float* brow = rg.bias[g] + ((long)h * rg.sb[g] + i) * rg.sb[g];
+      for (int j = 0; j < len; ++j) {
+        float s = brow[j], dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s += sq[i * D + d] * sk[j * D + d]; dp += sdo[i * D + d] * sv[j * D + d]; }
+        const float ds = __expf(s - sl[i]) * (dp - sd[i]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] += ds * sk[j * D + d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dq[row + d] = from_f<T>(acc[d] * scale);
+  }
+  for (int j = threadIdx.x; j < Sp; j += 64) {               // thread = key row: dk, dv
+    const long row = ((long)r * Sp + j) * E + h * D;
+    float ak[D], av[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+    if (j < len) {
+      const float* bcol = rg.bias[g] + (long)h * rg.sb[g] * rg.sb[g] + j;
+      for (int i = 0; i < len; ++i) {
+        float s = bcol[(long)i * rg.sb[g]], dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s += sq[i * D + d] * sk[j * D + d]; dp += sdo[i * D + d] * sv[j * D + d]; }
+        const float p = __expf(s - sl[i]);
+        const float ds = p * (dp - sd[i]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { av[d] += p * sdo[i * D + d]; ak[d] += ds * sq[i * D + d]; }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dk[row + d] = from_f<T>(ak[d]); dv[row + d] = from_f<T>(av[d]); }
+  }
+}
+
+// d(rel_pos_bias_g)[h][i][j] += sum over the rows of expert g of ds: one thread per (g, h, i, j) walks that expert's rows
+template <typename T, int D>
+__global__ void attn_rag_dbias_kernel(const T* dout, const T* q, const T* k, const T* v, const float* lse, const float* delta, RagA rg,
+                                      int Sp, int H, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rg.off[rg.ng]) return;
+  int g = 0;
+  while (g + 1 < rg.ng && idx >= rg.off[g + 1]) ++g;
+  const long e = idx - rg.off[g];
+  const int len = rg.len[g], Sb = rg.sb[g], E = H * D;
+  const int j = (int)(e % len), i = (int)((e / len) % len), h = (int)(e / ((long)len * len));
+  if (!rg.dbias[g]) return;
+  const float bv = rg.bias[g][((long)h * Sb + i) * Sb + j];
+  float acc = 0.f;
+  for (int r = rg.seg[g]; r < rg.seg[g + 1]; ++r) {
+    const T* qp = q + ((long)r * Sp + i) * E + h * D;
+    const T* dop = dout + ((long)r * Sp + i) * E + h * D;
+    const T* kp = k + ((long)r * Sp + j) * E + h * D;
+    const T* vp = v + ((long)r * Sp + j) * E + h * D;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s += to_f(qp[d]) * to_f(kp[d]); dp += to_f(dop[d]) * to_f(vp[d]); }
+    const long li = ((long)r * H + h) * Sp + i;
+    acc += __expf(s * scale + bv - lse[li]) * (dp - delta[li]);
+  }
+  rg.dbias[g][((long)h * Sb + i) * Sb + j] += acc;
+}
+
+static inline bool mk_raga(RagA& rg, const int* seg, const int* lens, const int* sb, const float* const* bias, float* const* dbias,
+                           int ng, int Sp, int H) {
+  if (!seg || !lens || !sb || !bias || ng < 1 || ng > HDMOE_MAX_GROUPS) return false;
+  rg.seg = seg; rg.ng = ng; rg.off[0] = 0;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const bool in = g < ng;
+    rg.len[g] = in ? lens[g] : 0; rg.sb[g] = in ? sb[g] : 0;
+    rg.bias[g] = in ? bias[g] : nullptr; rg.dbias[g] = (in && dbias) ? dbias[g] : nullptr;
+    if (in && (lens[g] < 1 || lens[g] > Sp || sb[g] < lens[g] || !bias[g])) return false;
+    rg.off[g + 1] = rg.off[g] + (in ? (long)H * lens[g] * lens[g] : 0);
+  }
+  return true;
+}
+template <typename T, int D>
+int attn_rag_fwd_launch(void* out, float* lse, const void* q, const void* k, const void* v, const RagA& rg, int R, int Sp, int H,
+                        hipStream_t st) {
+  int ml = 0;
+  for (int g = 0; g < rg.ng; ++g) ml = max(ml, rg.len[g]);
+  const size_t lds = (size_t)2 * ml * D * sizeof(float);
+  if (lds > 60 * 1024) return HDMOE_EINVAL;
+  hipLaunchKernelGGL((attn_rag_fwd_kernel<T, D>), dim3(R, H), dim3(64), lds, st, (T*)out, lse, (const T*)q, (const T*)k, (const T*)v, rg, Sp, H,
+                     1.f / sqrtf((float)D));
+  return hdmoe_launch_status();
+}
+template <typename T, int D>
+int attn_rag_bwd_launch(void* dq, void* dk, void* dv, float* delta, const void* dout, const void* out, const void* q, const void* k,
+                        const void* v, const float* lse, const RagA& rg, bool want_dbias, int R, int Sp, int H, hipStream_t st) {
+  int ml = 0;
+  for (int g = 0; g < rg.ng; ++g) ml = max(ml, rg.len[g]);
+  const size_t lds = (size_t)(4 * ml * D + 2 * ml) * sizeof(float);
+  if (lds > 60 * 1024) return HDMOE_EINVAL;
+  const float scale = 1.f / sqrtf((float)D);
+  hipLaunchKernelGGL((attn_rag_bwd_kernel<T, D>), dim3(R, H), dim3(64), lds, st, (T*)dq, (T*)dk, (T*)dv, delta, (const T*)dout, (const T*)out,
+                     (const T*)q, (const T*)k, (const T*)v, lse, rg, Sp, H, scale);
+  if (want_dbias)
+    hipLaunchKernelGGL((attn_rag_dbias_kernel<T, D>), dim3(cdiv(rg.off[rg.ng], 256)), dim3(256), 0, st, (const T*)dout, (const T*)q, (const T*)k,
+                       (const T*)v, lse, delta, rg, Sp, H, scale);
+  return hdmoe_launch_status();
+}
+
 }  // namespace
 
 #define D_SWITCH(D, CALL)                       \
@@ -622,6 +822,27 @@ int hdmoe_attn_bwd(void* dq, void* dk, void* dv, float* dbias, float* delta, con
   if (B < 1 || B > 65535 || H < 1 || H > 65535 || Sq < 1 || Skv < 1 || (bias && (Sb < Sq || Sb < Skv)) || (dbias && !bias)) return HDMOE_EINVAL;
   if (dtype == HDMOE_F32) { D_SWITCH(D, return (attn_bwd_launch<float, DD>(dq, dk, dv, dbias, delta, dout, out, q, k, v, lse, bias, B, Sq, Skv, H, Sb, stream))) }
   if (dtype == HDMOE_BF16) { D_SWITCH(D, return (attn_bwd_launch<bf16, DD>(dq, dk, dv, dbias, delta, dout, out, q, k, v, lse, bias, B, Sq, Skv, H, Sb, stream))) }
+  return HDMOE_EDTYPE;
+}
+
+/* Ragged self-attention of the ViT expert bank: q/k/v/out [R][Sp][H*D]; rows [seg[g], seg[g+1]) belong to expert g with lens[g]
+ * real tokens and the table bias[g] [H][sb[g]][sb[g]]; lse / delta [R][H][Sp].  dbias[g] (or null) accumulate (+=). */
+int hdmoe_attn_rag_fwd(void* out, float* lse, const void* q, const void* k, const void* v, const float* const* bias, const int* seg,
+                       const int* lens, const int* sb, int ngroups, int R, int Sp, int H, int D, int dtype, hipStream_t stream) {
+  RagA rg;
+  if (R < 1 || H < 1 || H > 65535 || !mk_raga(rg, seg, lens, sb, bias, nullptr, ngroups, Sp, H)) return HDMOE_EINVAL;
+  if (dtype == HDMOE_F32) { D_SWITCH(D, return (attn_rag_fwd_launch<float, DD>(out, lse, q, k, v, rg, R, Sp, H, stream))) }
+  if (dtype == HDMOE_BF16) { D_SWITCH(D, return (attn_rag_fwd_launch<bf16, DD>(out, lse, q, k, v, rg, R, Sp, H, stream))) }
+  return HDMOE_EDTYPE;
+}
+int hdmoe_attn_rag_bwd(void* dq, void* dk, void* dv, float* const* dbias, float* delta, const void* dout, const void* out,
+                       const void* q, const void* k, const void* v, const float* lse, const float* const* bias, const int* seg,
+                       const int* lens, const int* sb, int ngroups, int R, int Sp, int H, int D, int dtype, hipStream_t stream) {
+  RagA rg;
+  if (R < 1 || H < 1 || H > 65535 || !mk_raga(rg, seg, lens, sb, bias, dbias, ngroups, Sp, H)) return HDMOE_EINVAL;
+  const bool wd = dbias != nullptr;
+  if (dtype == HDMOE_F32) { D_SWITCH(D, return (attn_rag_bwd_launch<float, DD>(dq, dk, dv, delta, dout, out, q, k, v, lse, rg, wd, R, Sp, H, stream))) }
+  if (dtype == HDMOE_BF16) { D_SWITCH(D, return (attn_rag_bwd_launch<bf16, DD>(dq, dk, dv, delta, dout, out, q, k, v, lse, rg, wd, R, Sp, H, stream))) }
   return HDMOE_EDTYPE;
 }
 

@@ -1261,6 +1261,196 @@ def attention(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor], num_heads
 
 
 # =====================================================================================================
+# ragged tokens: the ViT expert bank (csrc/ragged.hip, hdmoe_attn_rag_* in csrc/attention.hip)
+# =====================================================================================================
+class RagLayout:
+    """Routed rows of all ViT experts in one padded tensor (R, Sp, C): rows [seg[g], seg[g+1]) (device int32, from the
+    dispatch plan) belong to expert g and hold ``lens[g]`` real tokens followed by padding."""
+
+    def __init__(self, seg: Tensor, lens: Sequence[int], R: int):
+        self.seg, self.lens, self.R = seg, [int(v) for v in lens], int(R)
+        self.G, self.Sp = len(self.lens), max(int(v) for v in lens)
+
+
+def _param_grads(params):
+    """(buffers the kernels accumulate into, what to hand back to autograd) for small fp32 parameters."""
+    direct = all(_direct(p) for p in params)
+    bufs = [p.grad if direct else torch.zeros_like(p) for p in params]
+    return bufs, ([None] * len(params) if direct else bufs)
+
+
+class _RagPackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rag, *tensors):
+        G = rag.G
+        srcs, pos = [_c(t) for t in tensors[:G]], tensors[G:]
+        C = srcs[0].shape[-1]
+        dst = torch.empty((rag.R, rag.Sp, C), dtype=srcs[0].dtype, device=srcs[0].device)
+        call("hdmoe_rag_pack", dst, srcs, [_f32(p) for p in pos], rag.seg, rag.lens, G, rag.R, rag.Sp, C, _dt(dst))
+        ctx.rag, ctx.C = rag, C
+        ctx.save_for_backward(*pos)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        rag, C, pos = ctx.rag, ctx.C, ctx.saved_tensors
+        g = _c(g)
+        dsrcs = [torch.empty((rag.R, L, C), dtype=g.dtype, device=g.device) for L in rag.lens]
+        bufs, ret = _param_grads(pos)
+        call("hdmoe_rag_pack_bwd", dsrcs, bufs, g, rag.seg, rag.lens, rag.G, rag.R, rag.Sp, C, _dt(g))
+        return (None, *dsrcs, *ret)
+
+
+def rag_pack(srcs: Sequence[Tensor], pos: Sequence[Tensor], rag: RagLayout) -> Tensor:
+    """Per-expert compact tokens (R, S_g, C) (+ that expert's pos_emb (1, S_g, C)) -> padded (R, Sp, C); row r takes expert g(r)'s."""
+    return _RagPackFn.apply(rag, *srcs, *pos)
+
+
+class _RagUnpackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, rag):
+        tok = _c(tok)
+        C = tok.shape[-1]
+        dsts = [torch.empty((rag.R, L, C), dtype=tok.dtype, device=tok.device) for L in rag.lens]
+        call("hdmoe_rag_unpack", dsts, tok, rag.seg, rag.lens, rag.G, rag.R, rag.Sp, C, _dt(tok))
+        ctx.rag, ctx.C = rag, C
+        return tuple(dsts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        rag, C = ctx.rag, ctx.C
+        ref = next(g for g in gs if g is not None)
+        gs = [_c(g) if g is not None else torch.zeros((rag.R, L, C), dtype=ref.dtype, device=ref.device) for g, L in zip(gs, rag.lens)]
+        d = torch.empty((rag.R, rag.Sp, C), dtype=ref.dtype, device=ref.device)
+        call("hdmoe_rag_unpack_bwd", d, gs, rag.seg, rag.lens, rag.G, rag.R, rag.Sp, C, _dt(d))
+        return d, None
+
+
+def rag_unpack(tok: Tensor, rag: RagLayout):
+    """Padded (R, Sp, C) -> one compact (R, S_g, C) tensor per expert (all rows: the caller selects each row's own expert later)."""
+    return _RagUnpackFn.apply(tok, rag)
+
+
+class _RagSelectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rag, *outs):
+        outs = [_c(o) for o in outs]
+        y = torch.empty_like(outs[0])
+        nb = y.numel() // rag.R * y.element_size()
+        call("hdmoe_rag_select", y, outs, rag.seg, rag.G, rag.R, nb)
+        ctx.rag, ctx.nb = rag, nb
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        douts = [torch.empty_like(g) for _ in range(ctx.rag.G)]
+        call("hdmoe_rag_select_bwd", douts, g, ctx.rag.seg, ctx.rag.G, ctx.rag.R, ctx.nb)
+        return (None, *douts)
+
+
+def rag_select(outs: Sequence[Tensor], rag: RagLayout) -> Tensor:
+    """y[r] = outs[g(r)][r] over same-shaped per-expert tensors (R, ...)."""
+    return _RagSelectFn.apply(rag, *outs)
+
+
+class _GNRagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rag, groups, act, eps, *params):
+        x = _c(x)
+        G = rag.G
+        C = x.shape[-1]
+        mean = torch.empty(rag.R * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        call("hdmoe_gn_rag_fwd", y, mean, rstd, x, list(params[:G]), list(params[G:]), rag.seg, rag.lens, G, rag.R, rag.Sp, C, groups, act, eps, _dt(x))
+        ctx.save_for_backward(x, mean, rstd, *params)
+        ctx.meta = (rag, groups, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, *params = ctx.saved_tensors
+        rag, groups, act = ctx.meta
+        G = rag.G
+        g = _c(g)
+        dx = torch.empty_like(x)
+        bufs, ret = _param_grads(params)
+        call("hdmoe_gn_rag_bwd", dx, bufs[:G], bufs[G:], g, x, list(params[:G]), list(params[G:]), mean, rstd, rag.seg, rag.lens, G, rag.R, rag.Sp,
+             x.shape[-1], groups, act, _dt(x))
+        return (dx, None, None, None, None, *ret)
+
+
+def gn_rag(x: Tensor, gammas: Sequence[Tensor], betas: Sequence[Tensor], rag: RagLayout, groups: int, act: int = 0, eps: float = 1e-5) -> Tensor:
+    """nn.GroupNorm (+ activation) over each row's REAL tokens with the row's expert's affine; padding -> 0."""
+    return _GNRagFn.apply(x, rag, int(groups), int(act), float(eps), *gammas, *betas)
+
+
+class _LNRagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rag, eps, *params):
+        x = _c(x)
+        G = rag.G
+        C = x.shape[-1]
+        mean = torch.empty(rag.R * rag.Sp, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        call("hdmoe_ln_rag_fwd", y, mean, rstd, x, list(params[:G]), list(params[G:]), rag.seg, G, rag.R, rag.Sp, C, eps, _dt(x))
+        ctx.save_for_backward(x, mean, rstd, *params)
+        ctx.rag = rag
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, *params = ctx.saved_tensors
+        rag = ctx.rag
+        G = rag.G
+        g = _c(g)
+        dx = torch.empty_like(x)
+        bufs, ret = _param_grads(params)
+        call("hdmoe_ln_rag_bwd", dx, bufs[:G], bufs[G:], g, x, list(params[:G]), mean, rstd, rag.seg, G, rag.R, rag.Sp, x.shape[-1], _dt(x))
+        return (dx, None, None, *ret)
+
+
+def ln_rag(x: Tensor, gammas: Sequence[Tensor], betas: Sequence[Tensor], rag: RagLayout, eps: float = 1e-5) -> Tensor:
+    """nn.LayerNorm per token with the row's expert's affine."""
+    return _LNRagFn.apply(x, rag, float(eps), *gammas, *betas)
+
+
+class _AttnRagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, rag, H, *biases):
+        q = _c(q); k = _c(k); v = _c(v)
+        R, Sp, E = q.shape
+        sb = [int(b.shape[-1]) for b in biases]
+        out = torch.empty_like(q)
+        lse = torch.empty((R, H, Sp), dtype=torch.float32, device=q.device)
+        call("hdmoe_attn_rag_fwd", out, lse, q, k, v, list(biases), rag.seg, rag.lens, sb, rag.G, R, Sp, H, E // H, _dt(q))
+        ctx.save_for_backward(q, k, v, out, lse, *biases)
+        ctx.meta = (rag, H, sb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse, *biases = ctx.saved_tensors
+        rag, H, sb = ctx.meta
+        g = _c(g)
+        R, Sp, E = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        bufs, ret = (None, [None] * rag.G)
+        if any(ctx.needs_input_grad[5:]):
+            bufs, ret = _param_grads(biases)
+        call("hdmoe_attn_rag_bwd", dq, dk, dv, bufs, delta, g, out, q, k, v, lse, list(biases), rag.seg, rag.lens, sb, rag.G, R, Sp, H, E // H, _dt(q))
+        return (dq, dk, dv, None, None, *ret)
+
+
+def attention_rag(q: Tensor, k: Tensor, v: Tensor, biases: Sequence[Tensor], rag: RagLayout, num_heads: int) -> Tensor:
+    """Self-attention over each row's real tokens with the row's expert's rel_pos_bias table (H, S_g, S_g)."""
+    return _AttnRagFn.apply(q, k, v, rag, int(num_heads), *biases)
+
+
+# =====================================================================================================
 # router head + dispatch
 # =====================================================================================================
 class _RouterHeadFn(torch.autograd.Function):

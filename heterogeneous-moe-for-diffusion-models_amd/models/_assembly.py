@@ -22,6 +22,11 @@ from models import model_internals as util
 Tensor = torch.Tensor
 
 
+# ViT experts as one routed bank over ragged token rows (one launch per layer for all experts; csrc/ragged.hip).
+# HDMOE_VIT_BANK=0: every expert on the whole batch on its own side stream (the round-1 path, kept for A/B timing).
+VIT_BANK = __import__("os").environ.get("HDMOE_VIT_BANK", "1") != "0"
+
+
 def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_emb: Tensor, text2d: Optional[Tensor],
                    kcap: Optional[int] = None) -> Tensor:
     """x channel-last (B,H,W,C) -> (B,H,W,C)."""
@@ -33,6 +38,13 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
         ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg)
+        return ops.combine_rows(ys, out_router, plan)
+    if VIT_BANK and m.vit_bank_compatible(mods, x.shape[1], x.shape[2]):
+        plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
+        xs = ops.gather_rows(x, plan)
+        ts = ops.gather_rows(time_emb, plan)
+        tx = None if text2d is None else ops.gather_rows(text2d, plan)
+        ys = m.vit_expert_bank_forward(mods, xs, ts, tx, plan.seg)
         return ops.combine_rows(ys, out_router, plan)
     return _combine_weighted(_run_experts(x, mods, time_emb, text2d), out_router)
 
@@ -160,13 +172,26 @@ class _HDMOEMBase(nn.Module):
         # the ViT experts need only the stem features: fork them now, they run beside the routers and the U-Net bank
         vit_mods = list(self.VIT_experts)
         vit_job = None
-        if not (all(isinstance(e, m.Unet_expert) for e in vit_mods) and len(vit_mods) <= 8):
+        banked = (all(isinstance(e, m.Unet_expert) for e in vit_mods) and len(vit_mods) <= 8) or \
+            (VIT_BANK and m.vit_bank_compatible(vit_mods, H, W))
+        if not banked:
             vit_job = _run_experts(ops.cast(in_vit, cdt), vit_mods, te, text2d)
         w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
+        side = None
+        if banked and ops.SIDE_STREAMS and x.is_cuda:
+            # the routed ViT bank (a few hundred small launches) runs beside the U-Net router and bank on its own stream
+            main = torch.cuda.current_stream()
+            side = ops.side_streams(x.device, 1)[0]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
+            wbank.note_forked_streams([side])
         w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
         out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
         if vit_job is not None:
             out_v = _combine_weighted(vit_job, w_vit)
+        elif side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         else:
             out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
         C = self.internal_channels

@@ -355,3 +355,95 @@ class Vit_expert(nn.Module):
 
     def forward(self, x: Tensor, time_emb: Tensor = None, text_emb: Optional[Tensor] = None) -> Tensor:
         return ops.from_nhwc(self._fwd(ops.to_nhwc(x), time_emb, text_emb))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ViT expert BANK: all experts of a layer in one launch over ragged (padded) token rows -- see csrc/ragged.hip.
+# ------------------------------------------------------------------------------------------------------------
+def vit_bank_compatible(experts: Sequence[nn.Module], H: int, W: int) -> bool:
+    """True when the experts differ only in patch size (the reference's HDMOEM construction, model_config1.py:120-127)."""
+    if not (1 <= len(experts) <= 8 and all(isinstance(e, Vit_expert) for e in experts)):
+        return False
+    e0 = experts[0]
+    b0 = e0.diffit[0] if len(e0.diffit) else None
+
+    def sig(e):
+        blk = [(b.res_balance, b.gain_s, b.gain_t, b.emb_dim, b.GN.num_groups, b.GN.num_channels, b.GN.eps, b.skip_proj is None,
+                b.TMSA.num_heads, b.TMSA.attn_balance, b.TMSA.time_dependent, b.norm1.eps, b.norm2.eps, b.resample) for b in e.diffit]
+        return (e.emb_dim, e.emb_balance, e.map_txt is None, e.norm.eps, e.patch.in_channels, tuple(blk),
+                None if e.map_txt is None else tuple(e.map_txt.weights.shape))
+    if any(sig(e) != sig(e0) for e in experts) or b0 is None or any(b.resample != "keep" for b in e0.diffit):
+        return False
+    for e in experts:
+        p = e.patch.kernel_size[0]
+        L = (-(-H // p)) * (-(-W // p))
+        if L != e.seq_ln or e.pos_emb.shape[1] != L or any(b.TMSA.rel_pos_bias.shape[1] < L for b in e.diffit):
+            return False
+    return True
+
+
+def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t: Optional[Tensor], rag) -> Tensor:
+    """Vit_block.forward (reference model_components.py:520-562) over a bank of blocks; tok (R, Sp, C) ragged rows, t (R, T)."""
+    b0 = blocks[0]
+    tr = b0.training
+    seg = rag.seg
+    bal = b0.res_balance
+    n = ((1.0 - bal) ** 2 + bal ** 2) ** 0.5
+
+    def lin(mods, inp, gain, **kw):
+        return ops.mp_conv(inp, [mm.weights for mm in mods], gain, seg=seg, training=tr, **kw)
+
+    res_main = tok
+    h = ops.gn_rag(tok, [b.GN.weight for b in blocks], [b.GN.bias for b in blocks], rag, b0.GN.num_groups, ops.ACT_MP_SILU, b0.GN.eps)
+    h = lin([b.linear1 for b in blocks], h, b0.gain_s)
+    res_attn = h
+    y = ops.ln_rag(h, [b.norm1.weight for b in blocks], [b.norm1.bias for b in blocks], rag, b0.norm1.eps)
+    # TMSA: time-modulated self-attention (MP_Attention.forward, reference model_internals.py:338-409)
+    at = [b.TMSA for b in blocks]
+    a0 = at[0]
+    q = lin([a.q_proj for a in at], y, b0.gain_s)
+    k = lin([a.k_proj for a in at], y, b0.gain_s)
+    v = lin([a.v_proj for a in at], y, b0.gain_s)
+    if a0.time_dependent and t is not None:
+        q = ops.seq_bcast_add(q, lin([a.q_time for a in at], t, b0.gain_t))
+        k = ops.seq_bcast_add(k, lin([a.k_time for a in at], t, b0.gain_t))
+        v = ops.seq_bcast_add(v, lin([a.v_time for a in at], t, b0.gain_t))
+    o = ops.attention_rag(q, k, v, [a.rel_pos_bias for a in at], rag, a0.num_heads)
+    ab = a0.attn_balance
+    an = ((1.0 - ab) ** 2 + ab ** 2) ** 0.5
+    y = lin([a.out_proj for a in at], o, b0.gain_s, res=y, alpha=ab / an, beta=(1.0 - ab) / an)
+    y = ops.mp_sum(y, res_attn, bal)
+    h = ops.ln_rag(y, [b.norm2.weight for b in blocks], [b.norm2.bias for b in blocks], rag, b0.norm2.eps)
+    h = ops.mp_silu(lin([b.linear2 for b in blocks], h, b0.gain_s))
+    h = lin([b.linear3 for b in blocks], h, b0.gain_s, res=y, alpha=(1.0 - bal) / n, beta=bal / n)
+    if b0.skip_proj is not None:
+        return lin([b.skip_proj for b in blocks], res_main, b0.gain_s, res=h, alpha=(1.0 - bal) / n, beta=bal / n)
+    return ops.mp_sum(res_main, h, bal)
+
+
+def vit_expert_bank_forward(experts: Sequence["Vit_expert"], x: Tensor, time_emb: Optional[Tensor], text_emb: Optional[Tensor],
+                            seg: Tensor) -> Tensor:
+    """Vit_expert.forward (reference model_components.py:655-706) over a bank of experts that differ in patch size.
+    x: (R,H,W,C) channel-last rows in expert-contiguous order (rows [seg[g], seg[g+1]) belong to expert g); time_emb (R,T) /
+    text_emb (R,text_dim) fp32.  Patch embedding and un-patching have per-expert shapes and run per expert over all rows (they
+    are <2 % of the bank's arithmetic); every layer in between is one launch for all experts."""
+    e0 = experts[0]
+    tr = e0.training
+    R, H, W, C = x.shape
+    ps = [e.patch.kernel_size[0] for e in experts]
+    rag = ops.RagLayout(seg, [(-(-H // p)) * (-(-W // p)) for p in ps], R)
+    pes = [ops.patch_embed(x, e.patch.weight, e.patch.bias) for e in experts]
+    tok = ops.rag_pack(pes, [e.pos_emb for e in experts], rag)
+    t = time_emb
+    if text_emb is not None:
+        tx = text_emb
+        if e0.map_txt is not None:
+            tx = ops.mp_conv(tx, [e.map_txt.weights for e in experts], seg=seg, training=tr)
+        t = ops.mp_sum(t, tx, e0.emb_balance)
+    for i in range(len(e0.diffit)):
+        tok = vit_block_bank_forward([e.diffit[i] for e in experts], tok, t, rag)
+    tok = ops.ln_rag(tok, [e.norm.weight for e in experts], [e.norm.bias for e in experts], rag, e0.norm.eps)
+    outs = []
+    for e, p, part in zip(experts, ps, ops.rag_unpack(tok, rag)):
+        outs.append(ops.pixel_shuffle_tokens(e.unpatch_proj._fwd(part), H, W, C, p))
+    return ops.rag_select(outs, rag)

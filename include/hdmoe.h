@@ -171,6 +171,43 @@ int hdmoe_attn_bwd(void* dq, void* dk, void* dv, float* dbias, float* delta, con
 int hdmoe_bicubic_fwd(float* out, const float* table, int H, int S0, int S, HS stream);
 int hdmoe_bicubic_bwd(float* dtable, const float* dout, int H, int S0, int S, HS stream);
 
+/* ---- ViT expert BANK: ragged tokens (csrc/ragged.hip, csrc/attention.hip) ----------------------------------------
+ * The reference evaluates its ViT experts one by one on the samples routed to each (model_config1.py:25-37,
+ * model_components.py:435-706).  The bank keeps all routed rows in one padded tensor [R][Sp][C]: rows [seg[g], seg[g+1])
+ * (device int32, from hdmoe_dispatch_plan) belong to expert g and hold lens[g] (host int array) real tokens followed by
+ * zero padding.  srcs / dsts / gamma / ... are host arrays of per-expert device pointers. */
+int hdmoe_rag_pack(void* dst, const void* const* srcs, const float* const* pos, const int* seg, const int* lens, int ngroups,
+                   int R, int Sp, int C, int dtype, HS stream);
+int hdmoe_rag_pack_bwd(void* const* dsrcs, float* const* dpos, const void* ddst, const int* seg, const int* lens, int ngroups,
+                       int R, int Sp, int C, int dtype, HS stream);
+int hdmoe_rag_unpack(void* const* dsts, const void* src, const int* seg, const int* lens, int ngroups, int R, int Sp, int C,
+                     int dtype, HS stream);
+int hdmoe_rag_unpack_bwd(void* dsrc, const void* const* ddsts, const int* seg, const int* lens, int ngroups, int R, int Sp,
+                         int C, int dtype, HS stream);
+int hdmoe_rag_select(void* y, const void* const* outs, const int* seg, int ngroups, int R, long row_bytes, HS stream);
+int hdmoe_rag_select_bwd(void* const* douts, const void* dy, const int* seg, int ngroups, int R, long row_bytes, HS stream);
+/* nn.GroupNorm(G, C) over each row's real tokens (+ act: 0 none, 1 relu, 2 mp_silu); mean / rstd [R][G] */
+int hdmoe_gn_rag_fwd(void* y, float* mean, float* rstd, const void* x, const float* const* gamma, const float* const* beta,
+                     const int* seg, const int* lens, int ngroups, int R, int Sp, int C, int G, int act, float eps, int dtype,
+                     HS stream);
+int hdmoe_gn_rag_bwd(void* dx, float* const* dgamma, float* const* dbeta, const void* dy, const void* x,
+                     const float* const* gamma, const float* const* beta, const float* mean, const float* rstd, const int* seg,
+                     const int* lens, int ngroups, int R, int Sp, int C, int G, int act, int dtype, HS stream);
+/* nn.LayerNorm(C) per token with the row's expert's affine; mean / rstd [R * Sp] */
+int hdmoe_ln_rag_fwd(void* y, float* mean, float* rstd, const void* x, const float* const* gamma, const float* const* beta,
+                     const int* seg, int ngroups, int R, int Sp, int C, float eps, int dtype, HS stream);
+int hdmoe_ln_rag_bwd(void* dx, float* const* dgamma, float* const* dbeta, const void* dy, const void* x,
+                     const float* const* gamma, const float* mean, const float* rstd, const int* seg, int ngroups, int R, int Sp,
+                     int C, int dtype, HS stream);
+/* self-attention over each row's real tokens with the expert's rel_pos_bias table bias[g] [H][sb[g]][sb[g]]
+ * (model_internals.py:374-404); lse / delta [R][H][Sp]; dbias[g] accumulate (+=), or dbias == NULL */
+int hdmoe_attn_rag_fwd(void* out, float* lse, const void* q, const void* k, const void* v, const float* const* bias,
+                       const int* seg, const int* lens, const int* sb, int ngroups, int R, int Sp, int H, int D, int dtype,
+                       HS stream);
+int hdmoe_attn_rag_bwd(void* dq, void* dk, void* dv, float* const* dbias, float* delta, const void* dout, const void* out,
+                       const void* q, const void* k, const void* v, const float* lse, const float* const* bias, const int* seg,
+                       const int* lens, const int* sb, int ngroups, int R, int Sp, int H, int D, int dtype, HS stream);
+
 /* ---- K1/K2: router head + dispatch  (model_components.py:155-168, model_config1.py:11-39) ---------------------- */
 int hdmoe_router_head_fwd(float* sparse, float* probs, float* xout, int* idx, const float* logits, const float* noise,
                           const float* mask, long B, int E, int k, HS stream);

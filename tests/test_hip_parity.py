@@ -268,6 +268,66 @@ def test_vit_expert_golden(golden_components, name, res, p):
         ve(torch.randn(1, 4, res + p, res, device=DEV), dev(c["te"])[:1], dev(c["text"])[:1])   # seq-len mismatch (:678)
 
 
+@pytest.mark.parametrize("dtype,rel", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("res,patches,k", [(10, [2, 4, 5, 4], 2), (16, [4, 8, 8, 16], 2), (8, [2, 4, 8], 1)])
+def test_vit_bank_matches_the_per_expert_path(dtype, rel, res, patches, k):
+    """The routed ragged-token ViT bank (csrc/ragged.hip: one launch per layer for all experts) against the per-expert path
+    (each Vit_expert on the whole batch, itself pinned to the reference by the golden tests above): outputs, input gradient
+    and every parameter gradient; one sample routes to fewer than k experts (unused rows) and one expert gets no sample."""
+    import copy
+    import hdmoe_hip
+    import models.model_components as mc
+    from models import _assembly as A
+    hdmoe_hip.set_compute_dtype(dtype)
+    torch.manual_seed(7)
+    E, B, C, T, TXT = len(patches), 6, 8, 6, 5
+    bank = torch.nn.ModuleList([mc.Vit_expert(num_heads=2, num_groups=2, in_channels=C, seq_ln=(-(-res // p)) ** 2, emb_dim=8, num_blocks=2,
+                                              patch_size=p, time_dim=T, text_dim=TXT) for p in patches]).to(DEV)
+    with torch.no_grad():
+        for n, prm in bank.named_parameters():
+            if "rel_pos_bias" in n or "pos_emb" in n:
+                prm.normal_(0, 0.5)
+            elif n.endswith(".bias") or ("norm" in n or "GN" in n) and n.endswith(".weight"):
+                prm.add_(0.3 * torch.randn_like(prm))
+    ref_bank = copy.deepcopy(bank)
+    x = torch.randn(B, C, res, res, device=DEV)
+    te, text = torch.randn(B, T, device=DEV), torch.randn(B, TXT, device=DEV)
+    w = torch.zeros(B, E, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    for b in range(B):
+        idx = torch.randperm(E - 1, generator=g)[:k] + (1 if b % 2 else 0)     # with E-1 choices shifted: expert usage is uneven
+        idx = idx.clamp(max=E - 2)                                              # the LAST expert never gets a sample
+        w[b, idx] = torch.rand(len(idx), generator=g).to(DEV) + 0.2
+    w[1] = 0.0
+    w[1, 0] = 1.0                                                               # one sample routed to a single expert (k = 2: one unused row)
+    gout = torch.randn(B, C, res, res, device=DEV)
+    res_out = {}
+    for mode, mods in (("bank", bank), ("per_expert", ref_bank)):
+        A.VIT_BANK = mode == "bank"
+        try:
+            xx = x.clone().requires_grad_(True)
+            ww = w.clone().requires_grad_(True)
+            xs = hdmoe_hip.ops.cast(hdmoe_hip.ops.to_nhwc(xx), dtype)
+            out = A._dispatch_nhwc(xs, mods, ww, te, text, kcap=k)
+            out = hdmoe_hip.ops.from_nhwc(out)
+            out.float().backward(gout)
+            res_out[mode] = (out.float(), xx.grad, ww.grad, {n: p.grad for n, p in mods.named_parameters()})
+        finally:
+            A.VIT_BANK = True
+    (o1, dx1, dw1, pg1), (o2, dx2, dw2, pg2) = res_out["bank"], res_out["per_expert"]
+    close_scaled(o1, o2, rel, msg="out")
+    close_scaled(dx1, dx2, rel, msg="dx")
+    close_scaled(dw1, dw2, rel, msg="d(router weights)")
+    gmax = max(float(v.abs().max()) for v in pg2.values() if v is not None)    # k_time gradients are mathematically 0 (softmax shift)
+    for n, gref in pg2.items():
+        last = n.startswith(f"{E - 1}.")
+        if pg1[n] is None or last:
+            assert gref is None or float(gref.abs().max()) == 0.0 or last, n
+            assert pg1[n] is None or float(pg1[n].abs().max()) == 0.0, n       # never-routed expert: no gradient
+        else:
+            close_scaled(pg1[n], gref, rel * 2, msg=n, atol=rel * 0.1 * gmax)
+
+
 def test_dispatch_empty_expert_golden(golden_components):
     import models.model_components as mc
     from models.model_config2 import router_to_unet_experts
