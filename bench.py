@@ -158,7 +158,7 @@ def roofline_leg(step_fn, n_steps):
     table = {k: dict(launches_per_step=v["n"] / n_steps, avg_us=1e3 * v["ms"] / v["n"], ms_per_step=v["ms"] / n_steps,
                      tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in agg.items()}
     table["_by_shape_ms_per_step"] = {k: [round(v[0] / n_steps, 3), v[1] / n_steps]
-                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:25]}
+                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:80]}
     tr = pmc_traffic(name)
     return dict(bound="mfma", kernel=name, dtype=a["dtype"], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                 traffic=tr, traffic_source=getattr(pmc_traffic, "source", None) if tr is not None else None,
@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default="", help="write the per-kernel table of the roofline leg to this JSON file")
+    ap.add_argument("--single-graph", action="store_true", help="capture the step as ONE hipGraph instead of the seven staged graphs (A/B)")
+    ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: synchronize after every step (the host never runs ahead of the GPU)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -261,14 +263,15 @@ def main():
     zeta = 0.1
 
     from hdmoe_hip import ops
-    from hdmoe_hip.graph import GraphedStep
+    from hdmoe_hip import graph as hgraph
+    from hdmoe_hip.graph import GraphedStep, StagedStep
 
     def fwd_bwd():
         buckets.zero_grad()
         out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["um"], Vit_router_mask=inp["vm"],
                     zeta=zeta, return_log_var=True, **inp["extra"])
         loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
-        loss["loss"].backward()
+        hgraph.backward(loss["loss"])                        # loss.backward(), or the staged backward sections (StagedStep)
         return loss["loss"].detach()
 
     def eager_step():
@@ -287,7 +290,7 @@ def main():
         # all-reduce stays outside the graph and runs right after the replay
         buckets.enabled = False                             # no collectives from autograd hooks while capturing
         try:
-            graphed = GraphedStep(fwd_bwd, device)
+            graphed = GraphedStep(fwd_bwd, device) if args.single_graph else StagedStep(fwd_bwd, device)
         except Exception as exc:                            # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
             graphed = None
@@ -316,6 +319,8 @@ def main():
         h0 = time.perf_counter()
         loss = step()
         host_s += time.perf_counter() - h0                   # host time to ENQUEUE a step (no sync inside)
+        if args.sync_each_step:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -326,6 +331,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
+    stage_ms = None
+    if not args.no_graph and graphed is not None and hasattr(graphed, "stage_times"):
+        graphed.timing = True                                # one extra, untimed step with HIP events between the staged graphs
+        step()
+        torch.cuda.synchronize()
+        stage_ms = graphed.stage_times()
+        graphed.timing = False
     mem_growth = torch.cuda.memory_allocated() - mem0
     gc.enable()
     loss_val = float(loss["loss"].detach())
@@ -384,7 +396,7 @@ def main():
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
-                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else "hipGraph replay", "optimizer": "excluded (metric is fwd+bwd)",
+                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else "hipGraph replay (7 staged graphs, expert branches on 2 streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},

@@ -1359,6 +1359,14 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     if (kh[s] * kw[s] > maxtaps) maxtaps = kh[s] * kw[s];
   }
   a.tap_lo = 0;
+  if (stride == 1 && !ones && maxtaps == 1 && Ho == H && Wo == W) {
+    bool plain = true;
+    for (int g = 0; g < ngroups; ++g) plain = plain && kh[g] == 1 && kw[g] == 1 && pt[g] == 0 && pl[g] == 0;
+    if (plain) {
+      const int rc = lwg_try_launch(x, dy, G, seg, ngroups, N, (long)H * W, Cin, Cout, dtype, stream);
+      if (rc <= 0) return rc;
+    }
+  }
   if (stride == 1) {
     // ---- v2: LDS-staged tiles of TH rows x TW columns (TH * TW <= 128 pixels); one launch per kernel-size class so the
     //      per-wave accumulator count (MAXT) matches the class (3x3 -> 3, 5x5 -> 7, 7x7 -> 13)

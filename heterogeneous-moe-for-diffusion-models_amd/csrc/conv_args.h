@@ -33,3 +33,7 @@ int conv6_try_launch(const ConvArgs& a, const ConvFuse* fuse, int dtype, hipStre
 
 // Split-bf16 variant for fp32 tensors (conv6s.hip): w = bf16 [hi | lo][g][tap][Cout][Cin], `wplane_elems` elements per plane.
 int conv6_split_try_launch(const ConvArgs& a, long wplane_elems, const ConvFuse* fuse, hipStream_t stream);
+
+// Pointwise (linear / 1x1, stride 1) weight gradient (lwgrad.hip): G[g] [Cout][Cin] fp32 slabs (+=).  Same return convention.
+int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, long HW, int Cin, int Cout,
+                   int dtype, hipStream_t stream);

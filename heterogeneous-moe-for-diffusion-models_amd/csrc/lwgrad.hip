@@ -1,0 +1,218 @@
+// Weight gradient of the POINTWISE layers (linear / 1x1 conv, stride 1): dW[g][o][i] += sum over the positions p of expert g's rows of
+// dy[p][o] * x[p][i]  (autograd of MP_Conv with kernel () or (1,1), reference models/model_internals.py:253-275).
+//
+// A third of the step's launches are such layers (ViT linears, q/k/v/out projections, time / text embeddings of every block, 1x1 skips),
+// and the tiled k x k kernel (conv.hip: conv_wgrad2) spent 20-40 us on each of them whatever their size: the contraction runs over
+// positions and there is no halo to share, so the work is a tall-skinny GEMM that should cost its HBM read.  Here a wave streams
+// 64-position slices of x and dy on its own:
+//   bf16: 16-byte loads -> wave-private LDS rows -> both MFMA operands by transposing reads (ds_read_b64_tr_b16), 32x32x16 MFMAs;
+//   fp32: no LDS at all -- for v_mfma_f32_32x32x2_f32 a lane supplies ONE element A[row = lane & 31][k = lane >> 5], which for
+//         position-major tensors is exactly a coalesced 128-byte row load per half-wave (exact fp32 products; these layers are tiny).
+// The four waves of a workgroup split the workgroup's slice range, add their accumulators through LDS and flush one [32*OT][32*IT]
+// tile with float atomics (the slab is shared with the other position partitions, as in conv_wgrad2).
+// Domain: Cin % 32 == 0, Cout % 32 == 0, no constant-one input channel; everything else stays with conv.hip.
+#include <stdlib.h>
+#include "common.h"
+#include "conv_args.h"
+#include "hdmoe.h"
+
+namespace {
+
+struct LwgArgs {
+  const void* x; const void* dy; float* G[HDMOE_MAX_GROUPS]; const int* seg;
+  int ngroups, N, I, O, upw;
+  long HW;
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_p4;
+
+// partition slot -> (expert, slice range): experts take ceil(slices / upw) consecutive slots each
+DEVI bool lwg_slot(const LwgArgs& a, int slot, int& g, long& p0, long& p1, long& u0, long& u1) {
+  for (g = 0; g < a.ngroups; ++g) {
+    const long r0 = a.seg ? a.seg[g] : 0, r1 = a.seg ? a.seg[g + 1] : a.N;
+    p0 = r0 * a.HW; p1 = r1 * a.HW;
+    const long units = (p1 - p0 + 63) >> 6;
+    const long nch = (units + a.upw - 1) / a.upw;
+    if (slot < nch) { u0 = (long)slot * a.upw; u1 = u0 + a.upw < units ? u0 + a.upw : units; return true; }
+    slot -= (int)nch;
+  }
+  return false;
+}
+
+template <int OT, int IT>
+DEVI void lwg_flush(f32x16 (&acc)[OT][IT], float* red, float* G, int o0, int i0, int I, int tid) {
+  // red: [4 waves][OT * IT][16 regs][64 lanes] floats; lane-major so that both the write and the summing read are conflict-free
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int u = 0; u < IT; ++u)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) red[((wave * OT * IT + t * IT + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
+  __syncthreads();
+  for (int e = tid; e < OT * IT * 1024; e += 256) {
+    const int l = e & 63, reg = (e >> 6) & 15, tu = e >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * OT * IT + tu) * 16 + reg) * 64 + l];
+    const int o = o0 + 32 * (tu / IT) + acc_row(reg, l), i = i0 + 32 * (tu % IT) + (l & 31);
+    atomicAdd(&G[(long)o * I + i], v);
+  }
+}
+
+template <int OT, int IT>
+__global__ __launch_bounds__(256) void lwg_bf16_kernel(LwgArgs a) {
+  // per wave: dy sub-tiles [OT][64 positions][64 B], x sub-tiles [IT][64][64 B]; reused for the cross-wave reduction at the end
+  constexpr int WB = (OT + IT) * 4096;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * 32 * IT, o0 = blockIdx.y * 32 * OT;
+  int g; long p0, p1, u0, u1;
+  if (!lwg_slot(a, blockIdx.z, g, p0, p1, u0, u1)) return;
+  const bf16* X = (const bf16*)a.x;
+  const bf16* DY = (const bf16*)a.dy;
+  unsigned char* mine = lds + wave * WB;
+  uint4 sdy[4 * OT], sx[4 * IT];
+  auto load = [&](long u) {
+    const long pb = p0 + (u << 6);
+#pragma unroll
+    for (int k = 0; k < 4 * OT; ++k) {
+      const int e = lane + 64 * k, q = e / (4 * OT), pc = e % (4 * OT);
+      const long p = pb + q;
+      sdy[k] = p < p1 ? *reinterpret_cast<const uint4*>(DY + p * a.O + o0 + pc * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4 * IT; ++k) {
+      const int e = lane + 64 * k, q = e / (4 * IT), pc = e % (4 * IT);
+      const long p = pb + q;
+      sx[k] = p < p1 ? *reinterpret_cast<const uint4*>(X + p * a.I + i0 + pc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4 * OT; ++k) {
+      const int e = lane + 64 * k, q = e / (4 * OT), pc = e % (4 * OT);
+      *reinterpret_cast<uint4*>(mine + (pc >> 2) * 4096 + q * 64 + (pc & 3) * 16) = sdy[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4 * IT; ++k) {
+      const int e = lane + 64 * k, q = e / (4 * IT), pc = e % (4 * IT);
+      *reinterpret_cast<uint4*>(mine + OT * 4096 + (pc >> 2) * 4096 + q * 64 + (pc & 3) * 16) = sx[k];
+    }
+  };
+  // transposing-read lane address inside a [rows][64 B] sub-tile: fragment = 8 consecutive positions (k) of channel lane & 31
+  const int h = lane >> 5, q4 = (lane & 15) >> 2, col4 = (lane & 16) + 4 * (lane & 3);
+  const int tlane = (8 * h + q4) * 64 + col4 * 2;
+  auto tr2 = [&](const unsigned char* base) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(base + 4 * 64));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  f32x16 acc[OT][IT];
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int u = 0; u < IT; ++u) acc[t][u] = (f32x16)(0.f);
+  const long iters = (u1 - u0 + 3) >> 2;
+  if (u0 + wave < u1) load(u0 + wave);
+  for (long it = 0; it < iters; ++it) {
+    const long u = u0 + wave + 4 * it;
+    const bool valid = u < u1;
+    if (valid) store();
+    __syncthreads();
+    if (u + 4 < u1) load(u + 4);
+    if (valid) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 fdy[OT], fx[IT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) fdy[t] = tr2(mine + t * 4096 + ks * 1024 + tlane);
+#pragma unroll
+        for (int v = 0; v < IT; ++v) fx[v] = tr2(mine + (OT + v) * 4096 + ks * 1024 + tlane);
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+          for (int v = 0; v < IT; ++v) acc[t][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy[t], fx[v], acc[t][v], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  lwg_flush<OT, IT>(acc, reinterpret_cast<float*>(lds), a.G[g], o0, i0, a.I, tid);
+}
+
+template <int OT, int IT>
+__global__ __launch_bounds__(256) void lwg_f32_kernel(LwgArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * 32 * IT, o0 = blockIdx.y * 32 * OT;
+  int g; long p0, p1, u0, u1;
+  if (!lwg_slot(a, blockIdx.z, g, p0, p1, u0, u1)) return;
+  const float* X = (const float*)a.x;
+  const float* DY = (const float*)a.dy;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[OT][IT];
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int u = 0; u < IT; ++u) acc[t][u] = (f32x16)(0.f);
+  // this wave's positions: the workgroup's range in 8-position steps, round-robin over the four waves
+  const long pa = p0 + (u0 << 6), pe = (p0 + (u1 << 6)) < p1 ? (p0 + (u1 << 6)) : p1;
+  for (long pb = pa + 8 * wave; pb < pe; pb += 32) {
+    float dv[4][OT], xv[4][IT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long p = pb + 2 * s + h;
+      const bool ok = p < pe;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) dv[s][t] = ok ? DY[p * a.O + o0 + 32 * t + r] : 0.f;
+#pragma unroll
+      for (int v = 0; v < IT; ++v) xv[s][v] = ok ? X[p * a.I + i0 + 32 * v + r] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int v = 0; v < IT; ++v) acc[t][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[s][t], xv[s][v], acc[t][v], 0, 0, 0);
+  }
+  lwg_flush<OT, IT>(acc, reinterpret_cast<float*>(lds), a.G[g], o0, i0, a.I, tid);
+}
+
+}  // namespace
+
+// Returns HDMOE_OK after launching, a negative status on a launch error, or 1 when the layer is outside this file's domain.
+int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, long HW, int Cin, int Cout,
+                   int dtype, hipStream_t stream) {
+  static const bool off = getenv("HDMOE_LWG") && atoi(getenv("HDMOE_LWG")) == 0;
+  if (off || Cin % 32 || Cout % 32 || (dtype != HDMOE_BF16 && dtype != HDMOE_F32)) return 1;
+  if (((uintptr_t)x | (uintptr_t)dy) & 15) return 1;
+  LwgArgs a;
+  a.x = x; a.dy = dy; a.seg = seg; a.ngroups = ngroups; a.N = N; a.HW = HW; a.I = Cin; a.O = Cout;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) a.G[g] = G[g < ngroups ? g : 0];
+  const int OT = Cout % 64 == 0 ? 2 : 1, IT = Cin % 64 == 0 ? 2 : 1;
+  const long ib = Cin / (32 * IT), ob = Cout / (32 * OT);
+  const long units = ((long)N * HW + 63) / 64 + ngroups;               // 64-position slices (upper bound over the experts' ragged ends)
+  long upw = (units * ib * ob + 511) / 512;                              // ~512 workgroups per launch
+  if (upw < 4) upw = 4;                                                  // at least one slice per wave
+  if (upw > 4096) upw = 4096;
+  a.upw = (int)upw;
+  const long slots = units / upw + ngroups + 1;
+  if (slots > 65535 || ob > 65535) return 1;
+  dim3 grid((unsigned)ib, (unsigned)ob, (unsigned)slots);
+  const size_t red = (size_t)4 * OT * IT * 4096;
+#define LWG_GO(KERNEL, LDS)                                                                                   \
+  do {                                                                                                        \
+    if (OT == 2 && IT == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, dim3(256), LDS, stream, a);               \
+    else if (OT == 2) hipLaunchKernelGGL((KERNEL<2, 1>), grid, dim3(256), LDS, stream, a);                     \
+    else if (IT == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(256), LDS, stream, a);                     \
+    else hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(256), LDS, stream, a);                                  \
+  } while (0)
+  if (dtype == HDMOE_BF16) {
+    const size_t stage = (size_t)4 * (OT + IT) * 4096;
+    const size_t lds = stage > red ? stage : red;
+    LWG_GO(lwg_bf16_kernel, lds);
+  } else {
+    LWG_GO(lwg_f32_kernel, red);
+  }
+  return hdmoe_launch_status();
+}

@@ -209,55 +209,92 @@ __global__ __launch_bounds__(TPB) void gn_rag_bwd_kernel(T* dx, MFPtrs dgamma, M
     for (int c = tid; c < C; c += TPB) { atomicAdd(&dgamma.p[g][c], sm[c]); atomicAdd(&dbeta.p[g][c], sm[C + c]); }
 }
 
-// ---------------------------------------------------------------- LayerNorm per token with per-expert affine; one wave per row of Sp tokens
-template <typename T>
-__global__ __launch_bounds__(64) void ln_rag_fwd_kernel(T* y, float* mean, float* rstd, const T* x, FPtrs gamma, FPtrs beta, Rag rg,
-                                                       int Sp, int C, float eps) {
-  const int r = blockIdx.x;
+// ---------------------------------------------------------------- LayerNorm per token with per-expert affine
+// One workgroup per row; 32 consecutive lanes own one token (lane l holds channels l, l + 32, ...: coalesced 64-byte rows at C = 32),
+// the per-token sums are 5-step butterflies inside the 32-lane half-wave, the parameter gradients accumulate per lane over the row's
+// tokens and leave the block as one atomic per channel.
+template <int CPL> DEVI float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T, int CPL>
+__global__ __launch_bounds__(TPB) void ln_rag_fwd_kernel(T* y, float* mean, float* rstd, const T* x, FPtrs gamma, FPtrs beta, Rag rg,
+                                                        int Sp, int C, float eps) {
+  const int r = blockIdx.x, l = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int g = rag_group(rg, r);
-  for (int s = threadIdx.x; s < Sp; s += 64) {
+  float ga[CPL], be[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = l + 32 * k;
+    ga[k] = (g >= 0 && c < C) ? gamma.p[g][c] : 0.f;
+    be[k] = (g >= 0 && c < C) ? beta.p[g][c] : 0.f;
+  }
+  const float ic = 1.f / (float)C;
+  for (int s = slot; s < Sp; s += TPB / 32) {
     const long t = (long)r * Sp + s;
-    const T* p = x + t * C;
-    float m = 0.f;
-    for (int c = 0; c < C; ++c) m += to_f(p[c]);
-    m /= (float)C;
+    float xv[CPL], m = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { const int c = l + 32 * k; xv[k] = c < C ? to_f(x[t * C + c]) : 0.f; m += xv[k]; }
+    m = half_sum<CPL>(m) * ic;
     float v = 0.f;
-    for (int c = 0; c < C; ++c) { const float d = to_f(p[c]) - m; v += d * d; }
-    const float rs = rsqrtf(v / (float)C + eps);
-    mean[t] = m; rstd[t] = rs;
-    for (int c = 0; c < C; ++c)
-      y[t * C + c] = from_f<T>(g >= 0 ? (to_f(p[c]) - m) * rs * gamma.p[g][c] + beta.p[g][c] : 0.f);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { const float d = (l + 32 * k < C) ? xv[k] - m : 0.f; v += d * d; }
+    const float rs = rsqrtf(half_sum<CPL>(v) * ic + eps);
+    if (l == 0) { mean[t] = m; rstd[t] = rs; }
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = l + 32 * k;
+      if (c < C) y[t * C + c] = from_f<T>(g >= 0 ? (xv[k] - m) * rs * ga[k] + be[k] : 0.f);
+    }
   }
 }
-template <typename T>
-__global__ __launch_bounds__(64) void ln_rag_bwd_kernel(T* dx, MFPtrs dgamma, MFPtrs dbeta, const T* dy, const T* x, FPtrs gamma,
-                                                       const float* mean, const float* rstd, Rag rg, int Sp, int C) {
-  extern __shared__ float sm[];                              // [2 * C]
-  const int r = blockIdx.x;
+template <typename T, int CPL>
+__global__ __launch_bounds__(TPB) void ln_rag_bwd_kernel(T* dx, MFPtrs dgamma, MFPtrs dbeta, const T* dy, const T* x, FPtrs gamma,
+                                                        const float* mean, const float* rstd, Rag rg, int Sp, int C) {
+  __shared__ float red[2][TPB / 32][32 * CPL];
+  const int r = blockIdx.x, l = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int g = rag_group(rg, r);
-  for (int c = threadIdx.x; c < 2 * C; c += 64) sm[c] = 0.f;
-  __syncthreads();
-  for (int s = threadIdx.x; s < Sp; s += 64) {
+  float ga[CPL], dg[CPL], db[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = l + 32 * k;
+    ga[k] = (g >= 0 && c < C) ? gamma.p[g][c] : 0.f;
+    dg[k] = 0.f; db[k] = 0.f;
+  }
+  const float ic = 1.f / (float)C;
+  for (int s = slot; s < Sp; s += TPB / 32) {
     const long t = (long)r * Sp + s;
-    if (g < 0) { for (int c = 0; c < C; ++c) dx[t * C + c] = from_f<T>(0.f); continue; }
     const float m = mean[t], rs = rstd[t];
-    float a1 = 0.f, a2 = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float gv = to_f(dy[t * C + c]), xh = (to_f(x[t * C + c]) - m) * rs;
-      a1 += gv * gamma.p[g][c];
-      a2 += gv * gamma.p[g][c] * xh;
-      atomicAdd(&sm[c], gv * xh);
-      atomicAdd(&sm[C + c], gv);
+    float gv[CPL], xh[CPL], a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = l + 32 * k;
+      gv[k] = (g >= 0 && c < C) ? to_f(dy[t * C + c]) : 0.f;
+      xh[k] = c < C ? (to_f(x[t * C + c]) - m) * rs : 0.f;
+      a1 += gv[k] * ga[k];
+      a2 += gv[k] * ga[k] * xh[k];
+      dg[k] += gv[k] * xh[k];
+      db[k] += gv[k];
     }
-    const float ic = 1.f / (float)C;
-    for (int c = 0; c < C; ++c) {
-      const float gv = to_f(dy[t * C + c]), xh = (to_f(x[t * C + c]) - m) * rs;
-      dx[t * C + c] = from_f<T>(rs * (gv * gamma.p[g][c] - ic * (a1 + xh * a2)));
+    a1 = half_sum<CPL>(a1); a2 = half_sum<CPL>(a2);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = l + 32 * k;
+      if (c < C) dx[t * C + c] = from_f<T>(rs * (gv[k] * ga[k] - ic * (a1 + xh[k] * a2)));     // g < 0: gv = ga = 0 -> 0
     }
   }
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) { red[0][slot][l + 32 * k] = dg[k]; red[1][slot][l + 32 * k] = db[k]; }
   __syncthreads();
   if (g >= 0)
-    for (int c = threadIdx.x; c < C; c += 64) { atomicAdd(&dgamma.p[g][c], sm[c]); atomicAdd(&dbeta.p[g][c], sm[C + c]); }
+    for (int e = threadIdx.x; e < 2 * C; e += TPB) {
+      const int which = e >= C, c = e - which * C;
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < TPB / 32; ++w) tot += red[which][w][c];
+      atomicAdd(which ? &dbeta.p[g][c] : &dgamma.p[g][c], tot);
+    }
 }
 
 static inline unsigned grid_for(long n) { long b = (n + TPB - 1) / TPB; if (b > 4096) b = 4096; if (b < 1) b = 1; return (unsigned)b; }
@@ -348,7 +385,13 @@ int hdmoe_ln_rag_fwd(void* y, float* mean, float* rstd, const void* x, const flo
   const int zeros[HDMOE_MAX_GROUPS] = {0};
   Rag rg; if (!mk_rag(rg, seg, zeros, ngroups)) return HDMOE_EINVAL;
   FPtrs ga, be; fill(ga, gamma, ngroups); fill(be, beta, ngroups);
-  RAG_DT(dtype, hipLaunchKernelGGL(ln_rag_fwd_kernel<T>, dim3(R), dim3(64), 0, stream, (T*)y, mean, rstd, (const T*)x, ga, be, rg, Sp, C, eps))
+#define LN_CPL(KERNEL, ...)                                                                          \
+  if (C <= 32) hipLaunchKernelGGL((KERNEL<T, 1>), dim3(R), dim3(TPB), 0, stream, __VA_ARGS__);       \
+  else if (C <= 64) hipLaunchKernelGGL((KERNEL<T, 2>), dim3(R), dim3(TPB), 0, stream, __VA_ARGS__);  \
+  else if (C <= 128) hipLaunchKernelGGL((KERNEL<T, 4>), dim3(R), dim3(TPB), 0, stream, __VA_ARGS__); \
+  else hipLaunchKernelGGL((KERNEL<T, 8>), dim3(R), dim3(TPB), 0, stream, __VA_ARGS__);
+  if (C < 1 || C > 256) return HDMOE_EINVAL;
+  RAG_DT(dtype, LN_CPL(ln_rag_fwd_kernel, (T*)y, mean, rstd, (const T*)x, ga, be, rg, Sp, C, eps))
   return hdmoe_launch_status();
 }
 int hdmoe_ln_rag_bwd(void* dx, float* const* dgamma, float* const* dbeta, const void* dy, const void* x, const float* const* gamma,
@@ -357,8 +400,8 @@ int hdmoe_ln_rag_bwd(void* dx, float* const* dgamma, float* const* dbeta, const 
   const int zeros[HDMOE_MAX_GROUPS] = {0};
   Rag rg; if (!mk_rag(rg, seg, zeros, ngroups)) return HDMOE_EINVAL;
   FPtrs ga; MFPtrs dg, db; fill(ga, gamma, ngroups); fill(dg, dgamma, ngroups); fill(db, dbeta, ngroups);
-  RAG_DT(dtype, hipLaunchKernelGGL(ln_rag_bwd_kernel<T>, dim3(R), dim3(64), 2 * C * sizeof(float), stream, (T*)dx, dg, db, (const T*)dy, (const T*)x, ga,
-                                   mean, rstd, rg, Sp, C))
+  if (C < 1 || C > 256) return HDMOE_EINVAL;
+  RAG_DT(dtype, LN_CPL(ln_rag_bwd_kernel, (T*)dx, dg, db, (const T*)dy, (const T*)x, ga, mean, rstd, rg, Sp, C))
   return hdmoe_launch_status();
 }
 

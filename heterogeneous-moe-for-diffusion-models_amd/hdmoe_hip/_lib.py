@@ -116,8 +116,13 @@ def _int_array(v: Sequence[int]):
 _ERR = {-1: "invalid argument", -2: "unsupported dtype", -3: "kernel launch failed"}
 
 
+CALL_LOG = None                                 # dev aid (tools/call_order.py): a list collects (entry point, stream id) per call
+
+
 def call(name: str, *args):
     """Invoke a C-ABI entry point on the current torch stream; raises on a non-zero status."""
+    if CALL_LOG is not None:
+        CALL_LOG.append((name, torch.cuda.current_stream().stream_id))
     sig = SIGNATURES[name]
     fn = getattr(lib(), name)
     if not sig.endswith("s"):

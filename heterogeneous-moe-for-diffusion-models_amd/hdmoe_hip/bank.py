@@ -37,6 +37,15 @@ def note_forked_streams(streams) -> None:
             FORKED_STREAMS.append(s)
 
 
+DEFER_FINISH = False
+PENDING: list = []
+
+
+def finish_pending() -> None:
+    while PENDING:
+        PENDING.pop()._finish()
+
+
 def join_forked_streams() -> None:
     if FORKED_STREAMS and torch.cuda.is_available():
         cur = torch.cuda.current_stream()
@@ -188,6 +197,10 @@ class WeightBank:
 
     def note_backward(self, ent: Entry):
         ent.used_bwd = True
+        if DEFER_FINISH:                                  # staged backward (graph.Stager): finished once, after the last section
+            if self not in PENDING:
+                PENDING.append(self)
+            return
         if not self._cb_queued:
             self._cb_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)

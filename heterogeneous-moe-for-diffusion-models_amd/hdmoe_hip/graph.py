@@ -33,3 +33,186 @@ class GraphedStep:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+# =====================================================================================================================================
+# Staged capture: one hipGraph per independent section of the step, replayed on separate streams.
+#
+# Inside ONE replayed hipGraph the two expert branches of HDMOEM (router + U-Net bank / router + ViT bank) do not overlap: measured
+# with rocprofv3 on MI355X (profiles/r02_*_timeline.txt), whichever way the fork is expressed (branch on a side stream, both branches on
+# side streams, either creation order) the runtime's graph executor ends up running the ViT backward after the U-Net backward,
+# DEBUG_HIP_FORCE_GRAPH_QUEUES / GPU_MAX_HW_QUEUES change nothing, and a single-stream capture has the same step time as a forked one.
+# The branches are independent between the stem and the fusion, and most of their kernels are far too small to fill 256 CUs, so the step
+# is cut at those two points -- in the forward AND in the backward -- into seven graphs:
+#
+#     pre (stem, scaling, time embedding)  ->  unet | vit  ->  post (fusion, head, loss, and their backward)
+#                                          ->  unet_bwd | vit_bwd  ->  pre_bwd (stem backward, weight-bank finish)
+#
+# and the host launches `unet` / `vit` (and the two backward graphs) on two streams, ordered by events.  Autograd is cut with
+# detached leaves at the stage boundaries; each backward section is an explicit torch.autograd.backward call over the boundary
+# tensors of its stage, so every section is captured on the stream its forward ran on.
+# =====================================================================================================================================
+class Stager:
+    """Stage bookkeeping shared by the eager warm-up runs and the capture run of a StagedStep.  Model code talks to it through
+    ``graph.current()``: ``cut(stage, **tensors_by_producer_stage)`` at a boundary, ``backward(loss)`` instead of loss.backward()."""
+
+    KIND = {"pre": "main", "unet": "u", "vit": "v", "post": "main", "unet_bwd": "u", "vit_bwd": "v", "pre_bwd": "main"}
+
+    def __init__(self, device, streams, pools):
+        self.device, self.streams, self.pools = device, streams, pools
+        self.capture = False
+        self.graphs = {}
+        self.stage = None
+        self._ctx = None
+        self.cuts = {"pre": [], "unet": [], "vit": []}          # producer stage -> [(tensor, detached leaf)]
+        self.order = []
+
+    # -- stage switching ------------------------------------------------------------------------------------------------------
+    def begin(self, name: str):
+        assert self.stage is None
+        st = self.streams[self.KIND[name]]
+        if self.capture:
+            g = torch.cuda.CUDAGraph()
+            self.graphs[name] = g
+            self._ctx = torch.cuda.graph(g, pool=self.pools[self.KIND[name]], stream=st)
+        else:
+            for other in self.streams.values():                  # warm-up: plain streams, fully ordered
+                st.wait_stream(other)
+            self._ctx = torch.cuda.stream(st)
+        self._ctx.__enter__()
+        self.stage = name
+        self.order.append(name)
+
+    def end(self):
+        if self.stage is not None:
+            self._ctx.__exit__(None, None, None)
+            self.stage, self._ctx = None, None
+
+    def cut(self, stage: str, **by_producer):
+        """End the current stage, begin ``stage``; tensors that need a gradient are replaced by detached leaves (their gradients
+        are fed to the producer stage's backward section later).  Returns the tensors in keyword order, flattened."""
+        self.end()
+        self.begin(stage)
+        out = []
+        for producer, tensors in by_producer.items():
+            for t in tensors:
+                if torch.is_tensor(t) and t.requires_grad:
+                    d = t.detach().requires_grad_(True)
+                    self.cuts[producer].append((t, d))
+                    out.append(d)
+                else:
+                    out.append(t)
+        return out
+
+    def _section(self, stage: str, producer: str):
+        self.end()
+        self.begin(stage)
+        pairs = [(t, d.grad) for t, d in self.cuts[producer] if d.grad is not None]
+        if pairs:
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
+    def backward(self, loss):
+        if "post" not in self.order:
+            raise RuntimeError("staged step: the model did not reach its stage boundaries (not the banked HDMOEM path)")
+        bank.DEFER_FINISH = True
+        try:
+            loss.backward()                                       # fusion + head + loss section; stops at the detached leaves
+            self._section("unet_bwd", "unet")
+            self._section("vit_bwd", "vit")
+            self._section("pre_bwd", "pre")
+        finally:
+            bank.DEFER_FINISH = False
+        bank.finish_pending()                                     # every weight gradient: one launch, in the last section
+
+
+_ACTIVE = None
+
+
+def current():
+    """The active Stager (inside a StagedStep run) or None."""
+    return _ACTIVE
+
+
+def backward(loss):
+    """loss.backward(), or the staged backward sections when a StagedStep is running."""
+    if _ACTIVE is not None:
+        _ACTIVE.backward(loss)
+    else:
+        loss.backward()
+
+
+class StagedStep:
+    """Drop-in for GraphedStep when ``step_fn`` runs the banked HDMOEM path and calls ``graph.backward(loss)``."""
+
+    ORDER = ["pre", "unet", "vit", "post", "unet_bwd", "vit_bwd", "pre_bwd"]
+
+    def __init__(self, step_fn, device, warmup: int = 3):
+        self.device = torch.device(device)
+        self.streams = {k: torch.cuda.Stream(device=self.device) for k in ("main", "u", "v")}
+        self.pools = {k: torch.cuda.graph_pool_handle() for k in ("main", "u", "v")}
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams.values():
+            s.wait_stream(cur)
+        for _ in range(warmup):
+            self._run(step_fn, capture=False)
+        for s in self.streams.values():
+            cur.wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        st = self._run(step_fn, capture=True)
+        if st.order != self.ORDER:
+            raise RuntimeError(f"staged step: unexpected stage sequence {st.order}")
+        self.graphs = st.graphs
+        self._keep = st                                           # boundary tensors live in the graphs' pools
+
+    def _run(self, step_fn, capture: bool):
+        global _ACTIVE
+        st = Stager(self.device, self.streams, self.pools)
+        st.capture = capture
+        _ACTIVE = st
+        try:
+            st.begin("pre")
+            ops.advance_seed(self.device)
+            self.out = step_fn()
+        finally:
+            try:
+                st.end()
+            finally:
+                _ACTIVE = None
+        return st
+
+    def __call__(self):
+        S, g = self.streams, self.graphs
+        main, u, v = S["main"], S["u"], S["v"]
+        cur = torch.cuda.current_stream(self.device)
+        ev = self._events = {} if self.timing else None
+
+        def run(name, stream):
+            with torch.cuda.stream(stream):
+                if ev is not None:
+                    ev[name] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[name][0].record(stream)
+                g[name].replay()
+                if ev is not None:
+                    ev[name][1].record(stream)
+
+        main.wait_stream(cur)
+        run("pre", main)
+        u.wait_stream(main); v.wait_stream(main)
+        run("unet", u)
+        run("vit", v)
+        main.wait_stream(u); main.wait_stream(v)
+        run("post", main)
+        u.wait_stream(main); v.wait_stream(main)
+        run("unet_bwd", u)
+        run("vit_bwd", v)
+        main.wait_stream(u); main.wait_stream(v)
+        run("pre_bwd", main)
+        cur.wait_stream(main)
+        return self.out
+
+    timing = False
+
+    def stage_times(self):
+        """(after a call with ``timing = True`` and a synchronize) {stage: (start ms, end ms)} relative to the start of `pre`."""
+        t0 = self._events["pre"][0]
+        return {k: (round(t0.elapsed_time(a), 3), round(t0.elapsed_time(b), 3)) for k, (a, b) in self._events.items()}

@@ -207,10 +207,11 @@ def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws
         kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
                                              ctypes.cast(_int_array(kws), ctypes.c_void_p), dtc)
         if kib > 0:
-            ws = _w6_ws.get(x.device)
+            key = (x.device, torch.cuda.current_stream().stream_id)       # branches on different streams run concurrently
+            ws = _w6_ws.get(key)
             if ws is None or ws.numel() < kib * 256:
                 ws = torch.empty(kib * 256, dtype=torch.float32, device=x.device)      # fp32 words; grown outside graph capture (warm-up steps)
-                _w6_ws[x.device] = ws
+                _w6_ws[key] = ws
             if split:
                 info = dict(info, dtype="split_bf16")
             if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc) == 0:

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 import hdmoe_hip
 from hdmoe_hip import bank as wbank
+from hdmoe_hip import graph as hgraph
 from hdmoe_hip import ops
 from models import model_components as m
 from models import model_internals as util
@@ -176,24 +177,40 @@ class _HDMOEMBase(nn.Module):
             (VIT_BANK and m.vit_bank_compatible(vit_mods, H, W))
         if not banked:
             vit_job = _run_experts(ops.cast(in_vit, cdt), vit_mods, te, text2d)
-        w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
-        side = None
-        if banked and ops.SIDE_STREAMS and x.is_cuda:
-            # the routed ViT bank (a few hundred small launches) runs beside the U-Net router and bank on its own stream
-            main = torch.cuda.current_stream()
+        st = hgraph.current()
+        if st is not None and banked and x.is_cuda:
+            # staged step (hdmoe_hip/graph.py): each branch is its own hipGraph on its own stream, cut out of autograd with detached
+            # leaves at the two boundaries; the backward sections are driven by Stager.backward
+            te_u, in_u = st.cut("unet", pre=(te, in_unet))
+            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_u, te_u, Unet_router_mask, zeta)
+            out_u = _dispatch_nhwc(ops.cast(in_u, cdt), self.Unet_experts, w_unet, te_u, text2d, kcap=self.top_k)
+            te_v, in_v = st.cut("vit", pre=(te, in_vit))
+            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_v, te_v, Vit_router_mask, zeta)
+            out_v = _dispatch_nhwc(ops.cast(in_v, cdt), self.VIT_experts, w_vit, te_v, text2d, kcap=self.top_k)
+            out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
+                "post", unet=(out_u, p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
+        elif banked and ops.SIDE_STREAMS and x.is_cuda:
+            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream())                        # the ViT bank depends on nothing issued after this point
+            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
+            out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
+            # the routed ViT bank (a few hundred small launches) on its own stream, beside the U-Net router and bank
             side = ops.side_streams(x.device, 1)[0]
-            side.wait_stream(main)
+            side.wait_event(fork)
             with torch.cuda.stream(side):
                 out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
             wbank.note_forked_streams([side])
-        w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
-        out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
-        if vit_job is not None:
-            out_v = _combine_weighted(vit_job, w_vit)
-        elif side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            out_v.record_stream(torch.cuda.current_stream())               # allocated on the side stream, consumed on this one
         else:
-            out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
+            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
+            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
+            out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
+            if vit_job is not None:
+                out_v = _combine_weighted(vit_job, w_vit)
+            else:
+                out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)
         C = self.internal_channels
         fu = out_u.reshape(B, H * W, C)                                     # channel-last image == (B, S, C) tokens
         fv = out_v.reshape(B, H * W, C)
