@@ -691,6 +691,32 @@ __global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, con
   }
 }
 
+// out = sum of up to 16 same-shaped tensors: the backward of a fan-out (a tensor consumed by n layers) in ONE pass -- autograd's own
+// accumulation is n - 1 separate add launches over the same data
+struct SumSrcs { const void* p[16]; };
+template <typename T>
+__global__ void sum_n_kernel(T* out, SumSrcs s, int n, long nv, long nelem) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    if ((v + 1) * W <= nelem) {
+      float f[W], g[W];
+      vload<T>(f, (const T*)s.p[0] + v * W);
+      for (int k = 1; k < n; ++k) {
+        vload<T>(g, (const T*)s.p[k] + v * W);
+#pragma unroll
+        for (int j = 0; j < W; ++j) f[j] += g[j];
+      }
+      vstore<T>(out + v * W, f);
+    } else {
+      for (long e = v * W; e < nelem; ++e) {
+        float f = 0.f;
+        for (int k = 0; k < n; ++k) f += to_f(((const T*)s.p[k])[e]);
+        out[e] = from_f<T>(f);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL)                    \
@@ -706,6 +732,14 @@ extern "C" {
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x) && al16(y)) L1D(axpby_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, (const T*)y, a, b, n / VT<T>::W);
                    else L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
+}
+int hdmoe_sum_n(void* out, const void* const* srcs, int n, long nelem, int dtype, hipStream_t stream) {
+  if (!out || !srcs || n < 1 || n > 16) return HDMOE_EINVAL;
+  SumSrcs s;
+  bool al = al16(out);
+  for (int k = 0; k < 16; ++k) { s.p[k] = srcs[k < n ? k : 0]; al = al && al16(s.p[k]); }
+  if (!al) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, L1D(sum_n_kernel<T>, (nelem + VT<T>::W - 1) / VT<T>::W, (T*)out, s, n, (nelem + VT<T>::W - 1) / VT<T>::W, nelem))
 }
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, L1D(affine_kernel<T>, n, (T*)out, (const T*)x, a, c, n))

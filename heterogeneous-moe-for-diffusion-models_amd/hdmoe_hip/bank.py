@@ -183,6 +183,8 @@ class WeightBank:
         global ACTIVE
         ACTIVE = self
         FORKED_STREAMS.clear()
+        from . import ops as _ops
+        _ops.zero_pool_reset(self.device)                 # one memset for all of this step's accumulate-into scratch
         if not self.entries:
             return
         if self._dirty:

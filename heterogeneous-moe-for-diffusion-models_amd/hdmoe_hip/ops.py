@@ -196,6 +196,88 @@ def _direct(p) -> bool:
 
 
 
+class _ZeroPool:
+    """Zero-initialised scratch for the backward kernels that ACCUMULATE (atomics) into a fresh buffer: ~50 such buffers per step
+    were 50 memset launches.  One persistent buffer per device, cleared by ONE memset at the start of a step (WeightBank.begin_step),
+    handed out in 256-byte-aligned slices.  Only for tensors that never become a leaf's .grad (autograd may adopt those)."""
+
+    def __init__(self, device, nbytes=32 << 20):
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+        self.high = 0
+
+    def reset(self):
+        if self.high:
+            self.buf[:(self.high + 255) // 256 * 256].view(torch.float32).zero_()      # (a byte-typed fill runs one byte per thread)
+        self.off = self.high = 0
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nb = n * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + 255) // 256 * 256
+        if start + nb > self.buf.numel():
+            return None
+        self.off = start + nb
+        self.high = max(self.high, self.off)
+        return self.buf[start:start + nb].view(dtype).view(*shape)
+
+
+_zero_pools = {}
+ZERO_POOL = _os.environ.get("HDMOE_ZERO_POOL", "1") != "0"
+
+
+def zero_pool_reset(device) -> None:
+    pool = _zero_pools.get(torch.device(device))
+    if pool is not None:
+        pool.reset()
+
+
+def _zeros(shape, dtype, device, pool_ok: bool = True) -> Tensor:
+    """torch.zeros for accumulate-into scratch / non-leaf gradients, served from the per-step zero pool when possible
+    (``pool_ok=False``: the buffer may become a leaf's .grad -- autograd adopts incoming gradients -- and must own its memory)."""
+    device = torch.device(device)
+    if pool_ok and ZERO_POOL and device.type == "cuda":
+        pool = _zero_pools.get(device)
+        if pool is None:
+            if torch.cuda.is_current_stream_capturing():
+                return torch.zeros(shape, dtype=dtype, device=device)
+            pool = _zero_pools[device] = _ZeroPool(device)
+        t = pool.take(tuple(shape), dtype)
+        if t is not None:
+            return t
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+class _FanoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_c(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        for i in range(0, len(gs), 15):                       # 16 sources per launch (the running sum takes one slot)
+            part = gs[i:i + 15] if i == 0 else [out] + gs[i:i + 15]
+            call("hdmoe_sum_n", out, part, len(part), out.numel(), _dt(out))
+        return out, None
+
+
+def fanout(x: Tensor, n: int):
+    """n aliases of ``x`` for n consumers: their gradients are summed by ONE kernel in the backward (autograd's own accumulation is
+    n - 1 separate add launches).  The aliases must not be modified in place."""
+    if n <= 1 or not (torch.is_tensor(x) and x.requires_grad):
+        return tuple(x for _ in range(max(n, 1)))
+    return _FanoutFn.apply(x, int(n))
+
+
 def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split=False):
     """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers -- and fp32 layers in
     split-bf16 mode (the router trunks) -- take the atomic-free kernel (csrc/wgrad6.hip) with a cached workspace; everything else
@@ -414,7 +496,7 @@ class _PatchEmbedFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             call("hdmoe_patch_relayout", dx, tok, N, H, W, C, p, hp, wp, 0, 1, _dt(x))
         if ctx.needs_input_grad[1]:
-            Gs = [torch.zeros((p * p, E, C), dtype=torch.float32, device=x.device)]
+            Gs = [_zeros((p * p, E, C), torch.float32, x.device)]
             call("hdmoe_conv_wgrad", x, dy, Gs, None, 1, N, H, W, hp, wp, C, C, E, p, 0, [p], [p], [0], [0], _dt(x))
             dw = torch.empty_like(w)
             call("hdmoe_wprep_bwd", [w], None, 1.0, Gs, [dw], None, [p], [p], 1, E, C, 0)
@@ -579,6 +661,7 @@ def sigmoid(x: Tensor, a: float = 1.0) -> Tensor:
 class _FilmSiluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, e, p, seed):
+        ctx.pool_ok = not e.is_leaf
         u = _c(u); e = _f32(e)
         N, C = u.shape[0], u.shape[-1]
         HW = u.numel() // (N * C)
@@ -599,7 +682,7 @@ class _FilmSiluFn(torch.autograd.Function):
         N, C = u.shape[0], u.shape[-1]
         HW = u.numel() // (N * C)
         du = torch.empty_like(u)
-        de = torch.zeros_like(e)
+        de = _zeros(e.shape, e.dtype, e.device, ctx.pool_ok)
         if p > 0.0:
             call("hdmoe_film_silu_drop_bwd", du, de, g, u, e, N, HW, C, seed, step_counter(u.device), p, _dt(u))
         else:
@@ -621,6 +704,7 @@ def film_silu(u: Tensor, e: Tensor, p: float = 0.0, training: bool = False) -> T
 class _ScaleRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s):
+        ctx.pool_ok = not s.is_leaf
         x = _c(x); s = _f32(s).reshape(-1)
         rows = x.shape[0]
         L = x.numel() // rows
@@ -636,7 +720,7 @@ class _ScaleRowsFn(torch.autograd.Function):
         rows = x.shape[0]
         L = x.numel() // rows
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        ds = torch.zeros_like(s) if ctx.needs_input_grad[1] else None
+        ds = _zeros(s.shape, s.dtype, s.device, ctx.pool_ok) if ctx.needs_input_grad[1] else None
         call("hdmoe_scale_rows_bwd", dx, ds, g, x, s, rows, L, _dt(x))
         return dx, ds
 
@@ -741,6 +825,7 @@ def seq_mean(x: Tensor) -> Tensor:
 class _SeqBcastAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, t):
+        ctx.pool_ok = not t.is_leaf
         x = _c(x); t = _f32(t)
         N, C = x.shape[0], x.shape[-1]
         S = x.numel() // (N * C)
@@ -755,7 +840,7 @@ class _SeqBcastAddFn(torch.autograd.Function):
         g = _c(g)
         dt_ = None
         if ctx.needs_input_grad[1]:
-            dt_ = torch.zeros((N, C), dtype=torch.float32, device=g.device)
+            dt_ = _zeros((N, C), torch.float32, g.device, ctx.pool_ok)
             call("hdmoe_seq_reduce", dt_, g, N, S, C, 1.0, _dt(g))
         return g, dt_
 
@@ -1129,7 +1214,7 @@ class _GroupNormFn(torch.autograd.Function):
         dbeta = beta.grad if direct else torch.zeros_like(beta)
         parts = _gn_parts(N, S, forward=False)
         if parts > 1:
-            ws = torch.zeros(2 * N * G, dtype=torch.float32, device=x.device)
+            ws = _zeros((2 * N * G,), torch.float32, x.device)
             call("hdmoe_groupnorm_bwd_split", dx, dgamma, dbeta, ws, parts, g, x, gamma, beta, mean, rstd, N, S, C, G, act, _dt(x))
         else:
             ws = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
@@ -1532,6 +1617,7 @@ def gather_rows(x: Tensor, plan: DispatchPlan) -> Tensor:
 class _CombineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ys, sparse, plan):
+        ctx.pool_ok = not sparse.is_leaf
         ys = _c(ys)
         L = ys.numel() // plan.R
         out = torch.empty((plan.B, *ys.shape[1:]), dtype=ys.dtype, device=ys.device)
@@ -1547,7 +1633,7 @@ class _CombineFn(torch.autograd.Function):
         g = _c(g)
         L = ys.numel() // plan.R
         dys = torch.empty_like(ys)
-        dsp = torch.zeros((plan.B, plan.E), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        dsp = _zeros((plan.B, plan.E), torch.float32, g.device, ctx.pool_ok) if ctx.needs_input_grad[1] else None
         call("hdmoe_combine_rows_bwd", dys, dsp, g, ys, plan.perm, plan.row_expert, plan.row_w, plan.R, plan.E, L, _dt(ys))
         return dys, dsp, None
 

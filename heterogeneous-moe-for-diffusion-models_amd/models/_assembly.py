@@ -182,11 +182,13 @@ class _HDMOEMBase(nn.Module):
             # staged step (hdmoe_hip/graph.py): each branch is its own hipGraph on its own stream, cut out of autograd with detached
             # leaves at the two boundaries; the backward sections are driven by Stager.backward
             te_u, in_u = st.cut("unet", pre=(te, in_unet))
-            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_u, te_u, Unet_router_mask, zeta)
-            out_u = _dispatch_nhwc(ops.cast(in_u, cdt), self.Unet_experts, w_unet, te_u, text2d, kcap=self.top_k)
+            (te_r, te_b), (in_r, in_b) = ops.fanout(te_u, 2), ops.fanout(in_u, 2)
+            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_r, te_r, Unet_router_mask, zeta)
+            out_u = _dispatch_nhwc(ops.cast(in_b, cdt), self.Unet_experts, w_unet, te_b, text2d, kcap=self.top_k)
             te_v, in_v = st.cut("vit", pre=(te, in_vit))
-            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_v, te_v, Vit_router_mask, zeta)
-            out_v = _dispatch_nhwc(ops.cast(in_v, cdt), self.VIT_experts, w_vit, te_v, text2d, kcap=self.top_k)
+            (te_r, te_b), (in_r, in_b) = ops.fanout(te_v, 2), ops.fanout(in_v, 2)
+            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_r, te_r, Vit_router_mask, zeta)
+            out_v = _dispatch_nhwc(ops.cast(in_b, cdt), self.VIT_experts, w_vit, te_b, text2d, kcap=self.top_k)
             out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
                 "post", unet=(out_u, p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
         elif banked and ops.SIDE_STREAMS and x.is_cuda:

@@ -129,7 +129,8 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
             x = conv("conv_skip", x)
         x, h = ops.pixel_norm_silu(x)
     else:
-        h = ops.mp_silu(x)
+        x, xh = ops.fanout(x, 2)                               # main branch + skip / residual: one fused gradient sum
+        h = ops.mp_silu(xh)
     y = conv("conv_res1", h, b0.conv_gain1)
     y = ops.film_silu(y, emb, b0.dropout, tr)                 # FiLM * emb -> mp_silu -> F.dropout, one pass
     if b0.type == "dec" and b0.conv_skip is not None:
@@ -184,19 +185,22 @@ def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_e
             text_emb = ops.seq_mean(text_emb)
         emb = ops.mp_sum(emb, conv([e.map_text for e in experts], text_emb), e0.label_balance)
     emb = ops.mp_silu(emb)
+    nblk = sum("conv" not in n for n in e0.encoders.keys()) + len(e0.decoders)
+    embs = list(ops.fanout(emb, nblk))                          # every block's emb_layer reads it: ONE gradient sum instead of nblk - 1 adds
     skips = []
     for name in e0.encoders.keys():
         mods = [e.encoders[name] for e in experts]
         if "conv" in name:
             x = conv(mods, x, ones=True)                         # torch.cat([x, ones]) folded into the conv (:416)
         else:
-            x = unet_block_bank_forward(mods, x, emb, seg)
-        skips.append(x)
+            x = unet_block_bank_forward(mods, x, embs.pop(), seg)
+        x, sk = ops.fanout(x, 2)
+        skips.append(sk)
     for name in e0.decoders.keys():
         mods = [e.decoders[name] for e in experts]
         if "block" in name:
             x = ops.mp_cat(x, skips.pop(), e0.concat_balance)
-        x = unet_block_bank_forward(mods, x, emb, seg)
+        x = unet_block_bank_forward(mods, x, embs.pop(), seg)
     return conv([e.out_conv for e in experts], x, [e.out_gain for e in experts])
 
 
@@ -393,27 +397,31 @@ def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t: Option
     def lin(mods, inp, gain, **kw):
         return ops.mp_conv(inp, [mm.weights for mm in mods], gain, seg=seg, training=tr, **kw)
 
-    res_main = tok
+    # every tensor with several consumers goes through ops.fanout: its gradient is then ONE fused sum, not n - 1 add launches
+    tok, res_main = ops.fanout(tok, 2)
     h = ops.gn_rag(tok, [b.GN.weight for b in blocks], [b.GN.bias for b in blocks], rag, b0.GN.num_groups, ops.ACT_MP_SILU, b0.GN.eps)
     h = lin([b.linear1 for b in blocks], h, b0.gain_s)
-    res_attn = h
+    h, res_attn = ops.fanout(h, 2)
     y = ops.ln_rag(h, [b.norm1.weight for b in blocks], [b.norm1.bias for b in blocks], rag, b0.norm1.eps)
     # TMSA: time-modulated self-attention (MP_Attention.forward, reference model_internals.py:338-409)
     at = [b.TMSA for b in blocks]
     a0 = at[0]
-    q = lin([a.q_proj for a in at], y, b0.gain_s)
-    k = lin([a.k_proj for a in at], y, b0.gain_s)
-    v = lin([a.v_proj for a in at], y, b0.gain_s)
+    yq, yk, yv, yr = ops.fanout(y, 4)
+    q = lin([a.q_proj for a in at], yq, b0.gain_s)
+    k = lin([a.k_proj for a in at], yk, b0.gain_s)
+    v = lin([a.v_proj for a in at], yv, b0.gain_s)
     if a0.time_dependent and t is not None:
-        q = ops.seq_bcast_add(q, lin([a.q_time for a in at], t, b0.gain_t))
-        k = ops.seq_bcast_add(k, lin([a.k_time for a in at], t, b0.gain_t))
-        v = ops.seq_bcast_add(v, lin([a.v_time for a in at], t, b0.gain_t))
+        tq, tk, tv = t if isinstance(t, (list, tuple)) else ops.fanout(t, 3)
+        q = ops.seq_bcast_add(q, lin([a.q_time for a in at], tq, b0.gain_t))
+        k = ops.seq_bcast_add(k, lin([a.k_time for a in at], tk, b0.gain_t))
+        v = ops.seq_bcast_add(v, lin([a.v_time for a in at], tv, b0.gain_t))
     o = ops.attention_rag(q, k, v, [a.rel_pos_bias for a in at], rag, a0.num_heads)
     ab = a0.attn_balance
     an = ((1.0 - ab) ** 2 + ab ** 2) ** 0.5
-    y = lin([a.out_proj for a in at], o, b0.gain_s, res=y, alpha=ab / an, beta=(1.0 - ab) / an)
+    y = lin([a.out_proj for a in at], o, b0.gain_s, res=yr, alpha=ab / an, beta=(1.0 - ab) / an)
     y = ops.mp_sum(y, res_attn, bal)
-    h = ops.ln_rag(y, [b.norm2.weight for b in blocks], [b.norm2.bias for b in blocks], rag, b0.norm2.eps)
+    y, yn = ops.fanout(y, 2)
+    h = ops.ln_rag(yn, [b.norm2.weight for b in blocks], [b.norm2.bias for b in blocks], rag, b0.norm2.eps)
     h = ops.mp_silu(lin([b.linear2 for b in blocks], h, b0.gain_s))
     h = lin([b.linear3 for b in blocks], h, b0.gain_s, res=y, alpha=(1.0 - bal) / n, beta=bal / n)
     if b0.skip_proj is not None:
@@ -432,7 +440,7 @@ def vit_expert_bank_forward(experts: Sequence["Vit_expert"], x: Tensor, time_emb
     R, H, W, C = x.shape
     ps = [e.patch.kernel_size[0] for e in experts]
     rag = ops.RagLayout(seg, [(-(-H // p)) * (-(-W // p)) for p in ps], R)
-    pes = [ops.patch_embed(x, e.patch.weight, e.patch.bias) for e in experts]
+    pes = [ops.patch_embed(xe, e.patch.weight, e.patch.bias) for xe, e in zip(ops.fanout(x, len(experts)), experts)]
     tok = ops.rag_pack(pes, [e.pos_emb for e in experts], rag)
     t = time_emb
     if text_emb is not None:
@@ -440,8 +448,10 @@ def vit_expert_bank_forward(experts: Sequence["Vit_expert"], x: Tensor, time_emb
         if e0.map_txt is not None:
             tx = ops.mp_conv(tx, [e.map_txt.weights for e in experts], seg=seg, training=tr)
         t = ops.mp_sum(t, tx, e0.emb_balance)
-    for i in range(len(e0.diffit)):
-        tok = vit_block_bank_forward([e.diffit[i] for e in experts], tok, t, rag)
+    nb = len(e0.diffit)
+    ts = list(ops.fanout(t, 3 * nb)) if (t is not None and e0.diffit[0].TMSA.time_dependent) else None
+    for i in range(nb):
+        tok = vit_block_bank_forward([e.diffit[i] for e in experts], tok, t if ts is None else ts[3 * i:3 * i + 3], rag)
     tok = ops.ln_rag(tok, [e.norm.weight for e in experts], [e.norm.bias for e in experts], rag, e0.norm.eps)
     outs = []
     for e, p, part in zip(experts, ps, ops.rag_unpack(tok, rag)):

@@ -1031,6 +1031,68 @@ def test_graph_replay_with_side_streams_matches_single_stream_eager():
     assert len(ref) > 400
 
 
+def test_staged_step_matches_plain_backward():
+    """hdmoe_hip/graph.py StagedStep: seven hipGraphs (stem / U-Net branch / ViT branch / fusion+loss+their backward / the two
+    branch backwards / stem backward), autograd cut at the stage boundaries with detached leaves, the branches replayed on two
+    streams -- must give the gradients of the plain single-stream eager step (eval mode: no dropout / logit noise), replay after
+    replay, for both model variants (config1 has the learned scaling net crossing from the first to the fourth stage)."""
+    import hdmoe_hip
+    from hdmoe_hip import ops, graph as hgraph
+    from hdmoe_hip.dp import GradBuckets
+    from Utils import configs
+    from Utils.utils import EDM_LOSS
+    from models import model_config1, model_config2
+    from oracle.recipe import fill_state, make_inputs
+    hdmoe_hip.set_compute_dtype(torch.float32)
+    crit = EDM_LOSS(num_experts=4, sigma_data=0.5, Unet_bal=0.05, vit_bal=0.1, z_bal=0.005, prior_bal=0.0)
+    for mod, extra in ((model_config1, {}), (model_config2, {"transition_point": 0.4, "softness": 0.3})):
+        kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
+        model = mod.preconditioned_HDMOEM(**kw)
+        model.load_state_dict(fill_state(model.state_dict(), 5))
+        model = model.to(DEV).eval()
+        inp = {k: v.to(DEV) for k, v in make_inputs(6, 4, 32, 4, 77, 768, 5).items()}
+        buckets = GradBuckets(model)
+
+        def fwd_bwd():
+            buckets.zero_grad()
+            out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["unet_mask"],
+                        Vit_router_mask=inp["vit_mask"], zeta=0.0, return_log_var=True, **extra)
+            loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+            hgraph.backward(loss["loss"])
+            return loss["loss"].detach()
+
+        saved = ops.SIDE_STREAMS
+        try:
+            ops.SIDE_STREAMS = False
+            for _ in range(2):
+                l_ref = fwd_bwd()
+            torch.cuda.synchronize()
+            ref = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.SIDE_STREAMS = saved
+        staged = hgraph.StagedStep(fwd_bwd, DEV, warmup=2)
+        assert sorted(staged.graphs) == sorted(hgraph.StagedStep.ORDER) and hgraph.current() is None
+        for _ in range(3):
+            l_g = staged()
+        torch.cuda.synchronize()
+        close(l_g, l_ref, rtol=1e-5, atol=1e-6, msg="loss")
+        bad = []
+        for n, p in model.named_parameters():
+            if n in ref:
+                scale = float(ref[n].abs().max())
+                err = float((p.grad - ref[n]).abs().max())
+                if err > 2e-4 * scale + 1e-7:
+                    bad.append((n, err, scale))
+        assert not bad, bad[:5]
+        assert len(ref) > 400
+        staged.timing = True
+        staged()
+        torch.cuda.synchronize()
+        t = staged.stage_times()
+        assert t["unet"][0] >= t["pre"][1] - 1e-3 and t["post"][0] >= max(t["unet"][1], t["vit"][1]) - 1e-3
+        assert t["pre_bwd"][0] >= max(t["unet_bwd"][1], t["vit_bwd"][1]) - 1e-3
+
+
 def test_full_size_batch_independence_and_router_invariants():
     """BASELINE config 2 at its FULL size (B = 256, bf16 experts, 4x32x32 latents, text 77x768), through properties that do not
     need the oracle at that size: routing is per sample, so a sample's output (bit for bit) and input-gradient must not depend
