@@ -37,3 +37,6 @@ int conv6_split_try_launch(const ConvArgs& a, long wplane_elems, const ConvFuse*
 // Pointwise (linear / 1x1, stride 1) weight gradient (lwgrad.hip): G[g] [Cout][Cin] fp32 slabs (+=).  Same return convention.
 int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, long HW, int Cin, int Cout,
                    int dtype, hipStream_t stream);
+
+// Pointwise forward / dgrad with Cin >= 1024 and Cout <= 64 (kgemm.hip).  Same return convention.
+int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);

@@ -456,6 +456,57 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
     return y.reshape(*shape[:-1], y.shape[-1])
 
 
+class _PatchLinearFn(torch.autograd.Function):
+    """Vit_expert.patch when the image divides into patches (model_components.py:670-679): a stride-p p x p conv is a linear layer on
+    the patch vectors, so: one relayout pass (image -> tokens of C*p*p features in the weight's own (c, i, j) order, the parameter
+    is used as the [E][C*p*p] matrix it already is in memory), then the long-contraction pointwise kernel (csrc/kgemm.hip), and in
+    the backward the streamed pointwise weight gradient (csrc/lwgrad.hip) -- instead of the generic strided conv kernels, whose
+    weight gradient alone cost 190 us per expert."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        N, H, W, C = x.shape
+        E, p = int(w.shape[0]), int(w.shape[2])
+        hp, wp, K = H // p, W // p, C * p * p
+        Epad = (E + 15) // 16 * 16
+        tok = torch.empty((N, hp, wp, K), dtype=x.dtype, device=x.device)
+        call("hdmoe_patch_relayout", tok, x, N, H, W, C, p, hp, wp, 1, 0, _dt(x))
+        wf = torch.empty(E * K, dtype=x.dtype, device=x.device)
+        wd = torch.empty(K * Epad, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+        call("hdmoe_wprep_fwd", [w], None, 1.0, [1], [1], 1, E, K, K, Epad, wf, wf.numel(), wd, 0 if wd is None else wd.numel(), 0, 0, 0, _dt(x))
+        y0 = torch.empty((N, hp, wp, E), dtype=x.dtype, device=x.device)
+        call("hdmoe_conv_fwd", tok, wf, y0, None, 1.0, 0.0, None, 1, wf.numel(), N, hp, wp, hp, wp, K, K, K, E, E, 1, 0, [1], [1], [0], [0], _dt(x))
+        y = torch.empty_like(y0)
+        call("hdmoe_bias_add", y, y0, b, N * hp * wp, E, _dt(x))
+        ctx.save_for_backward(tok, w)
+        ctx.wd = wd
+        ctx.dims = (N, H, W, C, E, p, hp, wp, K, Epad)
+        return y.reshape(N, hp * wp, E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, w = ctx.saved_tensors
+        N, H, W, C, E, p, hp, wp, K, Epad = ctx.dims
+        dy = _c(dy).reshape(N, hp, wp, E)
+        dt = _dt(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dtok = torch.empty((N, hp, wp, K), dtype=dy.dtype, device=dy.device)
+            call("hdmoe_conv_fwd", dy, ctx.wd, dtok, None, 1.0, 0.0, None, 1, ctx.wd.numel(), N, hp, wp, hp, wp, E, E, Epad, K, K, 1, 0, [1], [1], [0], [0], dt)
+            dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+            call("hdmoe_patch_relayout", dx, dtok, N, H, W, C, p, hp, wp, 1, 1, dt)
+        if ctx.needs_input_grad[1]:
+            Gs = [_zeros((1, E, K), torch.float32, dy.device)]
+            call("hdmoe_conv_wgrad", tok, dy, Gs, None, 1, N, hp, wp, hp, wp, K, K, E, 1, 0, [1], [1], [0], [0], dt)
+            dw = torch.empty_like(w)
+            call("hdmoe_wprep_bwd", [w], None, 1.0, Gs, [dw], None, [1], [1], 1, E, K, 0)
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros(E, dtype=torch.float32, device=dy.device)
+            call("hdmoe_colsum", db, dy, N * hp * wp, E, dt)
+        return dx, dw, db
+
+
 class _PatchEmbedFn(torch.autograd.Function):
     """Vit_expert.patch: nn.Conv2d(C, E, p, stride=p) with bias on the zero-padded image (model_components.py:670-679)."""
 
@@ -508,6 +559,10 @@ class _PatchEmbedFn(torch.autograd.Function):
 
 def patch_embed(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     """(N,H,W,C) -> tokens (N, ceil(H/p)*ceil(W/p), E)."""
+    p = int(w.shape[2])
+    if (x.shape[1] % p == 0 and x.shape[2] % p == 0 and w.shape[2] == w.shape[3] and w.is_contiguous()
+            and x.shape[3] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and (x.shape[3] * p * p) % 16 == 0):
+        return _PatchLinearFn.apply(x, w, b)
     return _PatchEmbedFn.apply(x, w, b)
 
 
