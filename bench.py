@@ -89,10 +89,13 @@ def pmc_traffic(kernel_name):
     if m:                                                   # rocprof prints bf16 instantiations mangled: IDF16b + Li<n>E / Lb<0|1>E
         args = "".join(("Lb1E" if a == "true" else "Lb0E" if a == "false" else f"Li{a}E") for a in m.group(2).split(", ") if a.strip("-").isdigit() or a in ("true", "false"))
         keys = [f"{m.group(1)}IDF16b{args}"]
-    for k, v in tbl.items():
+    keys = [k.split(" (")[0].replace("<split>", "") for k in keys]          # "wgrad6_kernel (+ reduce)" -> "wgrad6_kernel"
+    tot = n = 0.0
+    for k, v in tbl.items():                                # launch-weighted mean over the instantiations of the kernel
         if any(key in k for key in keys):
-            return round(v["hbm_read_bytes_per_launch_corrected"] + v["hbm_write_bytes_per_launch"])
-    return None
+            tot += (v["hbm_read_bytes_per_launch_corrected"] + v["hbm_write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
 
 
 def roofline_leg(step_fn, n_steps):
