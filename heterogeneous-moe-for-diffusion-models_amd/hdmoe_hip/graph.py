@@ -36,14 +36,11 @@ class GraphedStep:
 
 
 # =====================================================================================================================================
-# Staged capture: one hipGraph per independent section of the step, replayed on separate streams.
+# Staged capture: one hipGraph per independent section of the step, the two expert branches replayed on separate streams.
 #
-# Inside ONE replayed hipGraph the two expert branches of HDMOEM (router + U-Net bank / router + ViT bank) do not overlap: measured
-# with rocprofv3 on MI355X (profiles/r02_*_timeline.txt), whichever way the fork is expressed (branch on a side stream, both branches on
-# side streams, either creation order) the runtime's graph executor ends up running the ViT backward after the U-Net backward,
-# DEBUG_HIP_FORCE_GRAPH_QUEUES / GPU_MAX_HW_QUEUES change nothing, and a single-stream capture has the same step time as a forked one.
-# The branches are independent between the stem and the fusion, and most of their kernels are far too small to fill 256 CUs, so the step
-# is cut at those two points -- in the forward AND in the backward -- into seven graphs:
+# The two expert branches of HDMOEM (router + U-Net bank / router + ViT bank) are independent between the stem and the fusion, and
+# most of their kernels are far too small to fill 256 CUs.  The step is cut at those two points -- in the forward AND in the
+# backward -- into seven graphs:
 #
 #     pre (stem, scaling, time embedding)  ->  unet | vit  ->  post (fusion, head, loss, and their backward)
 #                                          ->  unet_bwd | vit_bwd  ->  pre_bwd (stem backward, weight-bank finish)
@@ -51,6 +48,14 @@ class GraphedStep:
 # and the host launches `unet` / `vit` (and the two backward graphs) on two streams, ordered by events.  Autograd is cut with
 # detached leaves at the stage boundaries; each backward section is an explicit torch.autograd.backward call over the boundary
 # tensors of its stage, so every section is captured on the stream its forward ran on.
+#
+# Measured on MI355X (BASELINE configs[1], same box, un-profiled): single stream 21.4 ms, ONE graph with the ViT bank forked onto a
+# side stream 19.4 ms, staged 19.2 ms.  So a fork inside one graph already overlaps; what the staged form adds is (a) ~1 % of step
+# time, (b) HIP events BETWEEN the graphs, i.e. per-stage GPU times without a profiler (`stage_times()`, bench.py "stage_ms"), and
+# (c) host-visible points between the backward sections where finished gradient buckets can be handed to RCCL while the rest of the
+# backward still runs.  A warning that cost hours: a rocprofv3 --kernel-trace timeline of the replay shows the branches strictly one
+# after the other -- the tracer adds ~17-20 us of host time per dispatch, the replay becomes host-bound and the queues drain in
+# issue order.  Branch overlap has to be read from events (stage_ms), not from the trace.
 # =====================================================================================================================================
 class Stager:
     """Stage bookkeeping shared by the eager warm-up runs and the capture run of a StagedStep.  Model code talks to it through
