@@ -326,6 +326,48 @@ __global__ __launch_bounds__(256) void wgrad6_reduce_kernel(W6Args a, W6Ptrs gp,
   }
 }
 
+// The same reduction for up to 16 (layer, kernel-size class) items in one launch: the weight bank defers every layer's reduction to the
+// end of the backward pass (each layer keeps its own workspace region until then), which turns ~64 few-microsecond launches per step
+// into four.  blockIdx.z = item, blockIdx.y = expert of the item's class.
+struct W6RItem {
+  const float* ws; const int* seg; float* G[HDMOE_MAX_GROUPS];
+  long ws_item;
+  int groups[HDMOE_MAX_GROUPS]; int ngr, N, tpi, upw;
+};
+struct W6RBatch { W6RItem it[16]; };
+__global__ __launch_bounds__(256) void wgrad6_reduce_multi_kernel(W6RBatch b) {
+  const W6RItem& a = b.it[blockIdx.z];
+  const int gi = blockIdx.y;
+  if (gi >= a.ngr) return;
+  int slot0 = 0, nch = 0;
+  for (int k = 0; k <= gi; ++k) {
+    const int g = a.groups[k];
+    const int units = ((a.seg ? a.seg[g + 1] : a.N) - (a.seg ? a.seg[g] : 0)) * a.tpi;
+    slot0 += nch;
+    nch = (units + a.upw - 1) / a.upw;
+  }
+  if (nch == 0) return;
+  float4* Gg = reinterpret_cast<float4*>(a.G[gi]);
+  const float4* W = reinterpret_cast<const float4*>(a.ws + (long)slot0 * a.ws_item);
+  const long stride4 = a.ws_item / 4, n4 = stride4;
+  const int part = threadIdx.x & 7;
+  for (long e0 = (long)blockIdx.x * 32; e0 < n4; e0 += (long)gridDim.x * 32) {
+    const long e = e0 + (threadIdx.x >> 3);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4)
+      for (int c = part; c < nch; c += 8) { const float4 v = W[c * stride4 + e]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s.x += __shfl_xor(s.x, o, 8); s.y += __shfl_xor(s.y, o, 8); s.z += __shfl_xor(s.z, o, 8); s.w += __shfl_xor(s.w, o, 8);
+    }
+    if (part == 0 && e < n4) {
+      float4 o = Gg[e];
+      o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+      Gg[e] = o;
+    }
+  }
+}
+
 // Pixel partitioning of one kernel-size class: upw tiles per workgroup, `slots` partition slots (an upper bound that holds for any
 // routing: sum over the class's experts of ceil(units_g / upw) <= units_l / upw + ngr).
 void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw, int& slots) {
@@ -377,11 +419,14 @@ int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout
 // Returns 1 when the shape is outside the domain (nothing launched).
 int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin,
                       int Cout, const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, int dtype,
-                      hipStream_t stream) {
+                      int defer, hipStream_t stream) {
   static const bool off = getenv("HDMOE_WGRAD6") && atoi(getenv("HDMOE_WGRAD6")) == 0;
   if (off) return 1;
-  const long need = 1024l * hdmoe_conv_wgrad6_ws_kib(ngroups, N, H, W, Cin, Cout, kh, kw, dtype);
-  if (need == 0 || !ws || ws_bytes < need || !x || !dy || !G) return 1;
+  // defer != 0: no reduction here (hdmoe_conv_wgrad6_reduce_batch does it later); the kernel-size classes then need their own
+  // workspace regions, laid out one after the other (each `need` bytes at most)
+  const long need1 = 1024l * hdmoe_conv_wgrad6_ws_kib(ngroups, N, H, W, Cin, Cout, kh, kw, dtype);
+  const long need = defer ? 2 * need1 : need1;
+  if (need1 == 0 || !ws || ws_bytes < need || !x || !dy || !G) return 1;
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) return 1;
   for (int g = 0; g < ngroups; ++g) if (((uintptr_t)G[g] & 15) || pt[g] != (kh[g] - 1) / 2 || pl[g] != (kw[g] - 1) / 2) return 1;
   const int esz = dtype == HDMOE_F32S ? 4 : 2;
@@ -397,6 +442,7 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
   const long units_l = (long)N * a.tpi;
   bool done[HDMOE_MAX_GROUPS] = {false};
+  int cls = 0;
   for (int g = 0; g < ngroups; ++g) {
     if (done[g]) continue;
     a.ngr = 0;
@@ -404,6 +450,11 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
       if (!done[g2] && kh[g2] == kh[g]) { a.groups[a.ngr++] = g2; done[g2] = true; }
     const int ks = kh[g];
     a.pt = pt[g]; a.pl = pl[g];
+    if (defer) {
+      if (cls >= 2) return HDMOE_EINVAL;                       // (the domain has two kernel sizes)
+      a.ws = (float*)((char*)ws + (long)cls * need1);
+    }
+    ++cls;
     a.ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
     w6_partition(units_l, a.ngr, ngroups, ibs, obs, upw, slots);
@@ -415,12 +466,59 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
       else { if (OT == 2) launch_w6<3, 4, 2, true>(b, ibs, obs, stream); else launch_w6<3, 4, 1, true>(b, ibs, obs, stream); }
     } else if (ks == 3) { if (TWS == 5) { if (OT == 2) W6_LAUNCH(3, 5, 2); else W6_LAUNCH(3, 5, 1); } else { if (OT == 2) W6_LAUNCH(3, 4, 2); else W6_LAUNCH(3, 4, 1); } }
     else { if (TWS == 5) { if (OT == 2) W6_LAUNCH(5, 5, 2); else W6_LAUNCH(5, 5, 1); } else { if (OT == 2) W6_LAUNCH(5, 4, 2); else W6_LAUNCH(5, 4, 1); } }
+    if (defer) continue;
     W6Ptrs gp;
     for (int k = 0; k < HDMOE_MAX_GROUPS; ++k) gp.G[k] = k < b.ngr ? G[b.groups[k]] : nullptr;
     const long n4 = b.ws_item / 4;
     const long rblocks = (n4 + 31) / 32;
     hipLaunchKernelGGL(wgrad6_reduce_kernel, dim3((unsigned)(rblocks < 2048 ? rblocks : 2048), b.ngr), dim3(256), 0, stream, b, gp, n4);
   }
+  return hdmoe_launch_status();
+}
+
+// Deferred reductions of `n` hdmoe_conv_wgrad6(..., defer = 1) calls, 16 (layer, class) items per launch.  Per call i: G + 8 i (its
+// per-expert slabs), seg[i], ws[i] (the workspace it was given) and dims + 16 i = {ngroups, N, H, W, Cin, Cout, dtype, 0, kh[0..7]}.
+int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, hipStream_t stream) {
+  if (n < 0 || (n && (!G || !seg || !ws || !dims))) return HDMOE_EINVAL;
+  W6RBatch batch;
+  int fill = 0;
+  long maxn4 = 0;
+  auto flush = [&]() {
+    if (!fill) return;
+    for (int k = fill; k < 16; ++k) { batch.it[k] = batch.it[0]; batch.it[k].ngr = 0; }
+    const long rblocks = (maxn4 + 31) / 32;
+    hipLaunchKernelGGL(wgrad6_reduce_multi_kernel, dim3((unsigned)(rblocks < 256 ? rblocks : 256), HDMOE_MAX_GROUPS, fill), dim3(256), 0, stream, batch);
+    fill = 0; maxn4 = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const int* d = dims + 16 * i;
+    const int ngroups = d[0], N = d[1], H = d[2], W = d[3], Cin = d[4], Cout = d[5], dtype = d[6];
+    const int* kh = d + 8;
+    const long need1 = 1024l * hdmoe_conv_wgrad6_ws_kib(ngroups, N, H, W, Cin, Cout, kh, kh, dtype);
+    if (need1 == 0 || !ws[i]) return HDMOE_EINVAL;
+    const int TW = W >= 32 ? 32 : 16, TH = 256 / TW, OT = Cout % 64 == 0 ? 2 : 1;
+    const int tpi = (W / TW) * (int)cdiv(H, TH);
+    const long units_l = (long)N * tpi;
+    bool done[HDMOE_MAX_GROUPS] = {false};
+    int cls = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      if (done[g]) continue;
+      W6RItem& it = batch.it[fill];
+      it.ngr = 0;
+      for (int g2 = g; g2 < ngroups; ++g2)
+        if (!done[g2] && kh[g2] == kh[g]) { it.groups[it.ngr] = g2; it.G[it.ngr] = G[8 * i + g2]; ++it.ngr; done[g2] = true; }
+      for (int k = it.ngr; k < HDMOE_MAX_GROUPS; ++k) { it.groups[k] = 0; it.G[k] = nullptr; }
+      int upw, slots;
+      w6_partition(units_l, it.ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots);
+      it.ws = (const float*)((const char*)ws[i] + (long)cls * need1);
+      it.seg = seg[i]; it.N = N; it.tpi = tpi; it.upw = upw;
+      it.ws_item = (long)kh[g] * kh[g] * Cout * Cin;
+      if (it.ws_item / 4 > maxn4) maxn4 = it.ws_item / 4;
+      ++cls;
+      if (++fill == 16) flush();
+    }
+  }
+  flush();
   return hdmoe_launch_status();
 }
 

@@ -22,7 +22,7 @@ MAX_GROUPS = 8
 #   I host int array (list of ints)       F host float array     i int   l long   f float   u unsigned long long   s stream
 # The table is derived from include/hdmoe.h itself, so the binding cannot drift from the declared C ABI.
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "hdmoe.h"))
-_HOST_INT_ARRAYS = {"kh", "kw", "pt", "pl", "lens", "sb"}
+_HOST_INT_ARRAYS = {"kh", "kw", "pt", "pl", "lens", "sb", "dims"}
 _HOST_FLOAT_ARRAYS = {"group_lr", "group_wd"}
 
 

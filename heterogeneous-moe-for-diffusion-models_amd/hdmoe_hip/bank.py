@@ -185,6 +185,8 @@ class WeightBank:
         FORKED_STREAMS.clear()
         from . import ops as _ops
         _ops.zero_pool_reset(self.device)                 # one memset for all of this step's accumulate-into scratch
+        _ops.w6_arena_reset(self.device)
+        self._w6_pending = []
         if not self.entries:
             return
         if self._dirty:
@@ -207,10 +209,21 @@ class WeightBank:
             self._cb_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
 
+    def defer_w6(self, Gs, seg, ws, dims):
+        """A k x k layer left its partial weight-gradient slabs in `ws` (ops._wgrad): summed in _finish."""
+        self._w6_pending.append((Gs, seg, ws, dims))
+
     def _finish(self):
         """Runs once at the end of the backward pass: all weight gradients in one launch."""
         self._cb_queued = False
         join_forked_streams()
+        pend, self._w6_pending = getattr(self, "_w6_pending", []), []
+        if pend:                                           # deferred wgrad6 reductions: one launch per 16 (layer, kernel-size class) items
+            Gflat, segs, wss, dims = [], [], [], []
+            for Gs, seg, ws, d in pend:
+                Gflat += list(Gs) + [None] * (8 - len(Gs))
+                segs.append(seg); wss.append(ws); dims += d
+            call("hdmoe_conv_wgrad6_reduce_batch", Gflat, segs, wss, dims, len(pend))
         call("hdmoe_wbank_bwd", self._descs, self._rows, self._nrows)
 
 

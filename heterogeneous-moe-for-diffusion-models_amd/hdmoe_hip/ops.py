@@ -126,7 +126,7 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys, split=False):
     if c6 is not None:
         tname = "float" if x.dtype == torch.float32 else "__bf16"
         return dict(dtype=c6[1], seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)], fwd_name=c6[0],
-                    wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws)))))
+                    wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws))), I, cphys == I))
     esz = x.element_size()
     vec = cphys % (16 // esz) == 0
     tname = "float" if x.dtype == torch.float32 else "__bf16"
@@ -157,11 +157,13 @@ def _conv_info(x, seg, N, Ho, Wo, O, I, Cstore, khs, kws, cphys, split=False):
         nb = 1 if Cstore <= 32 else (2 if Cstore <= 64 else 4)
         fwd_name = f"conv_fwd_kernel<{tname}, {nb}, {'true' if vec else 'false'}>"
     return dict(dtype=str(x.dtype).replace("torch.", ""), seg=seg, N=N, HW=Ho * Wo, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)],
-                fwd_name=fwd_name, wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws)))))
+                fwd_name=fwd_name, wgrad_name=_wgrad_name(tname, O, sorted(set(a * b for a, b in zip(khs, kws))), I, cphys == I))
 
 
-def _wgrad_name(tname, O, tap_classes):
+def _wgrad_name(tname, O, tap_classes, I=0, plain=False):
     """Kernel instantiation(s) hdmoe_conv_wgrad picks (mirrors csrc/conv.hip: one launch per kernel-size class)."""
+    if plain and tap_classes == [1] and O % 32 == 0 and I % 32 == 0:          # pointwise layers: csrc/lwgrad.hip
+        return f"lwg_{'f32' if tname == 'float' else 'bf16'}_kernel<{2 if O % 64 == 0 else 1}, {2 if I % 64 == 0 else 1}>"
     names = []
     for taps in tap_classes:
         passes = (taps + 27) // 28 if taps > 28 else 1
@@ -278,7 +280,45 @@ def fanout(x: Tensor, n: int):
     return _FanoutFn.apply(x, int(n))
 
 
-def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split=False):
+class _W6Arena:
+    """Workspace of the DEFERRED wgrad6 reductions: every k x k layer of the weight bank keeps its partial slabs until the end of the
+    backward pass, where one batched launch per 16 layers sums them (WeightBank._finish).  One bump-allocated buffer per device,
+    rewound at the start of a step; HDMOE_W6_ARENA_MB (default 4096) of the 288 GB."""
+
+    def __init__(self, device):
+        mb = int(_os.environ.get("HDMOE_W6_ARENA_MB", "4096"))
+        self.buf = torch.empty(mb << 18, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, nfloats):
+        start = (self.off + 63) // 64 * 64
+        if start + nfloats > self.buf.numel():
+            return None
+        self.off = start + nfloats
+        return self.buf[start:start + nfloats]
+
+
+_w6_arenas = {}
+W6_DEFER = _os.environ.get("HDMOE_W6_DEFER", "1") != "0"
+
+
+def w6_arena_reset(device) -> None:
+    a = _w6_arenas.get(torch.device(device))
+    if a is not None:
+        a.off = 0
+
+
+def _w6_arena_take(device, nfloats):
+    device = torch.device(device)
+    a = _w6_arenas.get(device)
+    if a is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        a = _w6_arenas[device] = _W6Arena(device)
+    return a.take(nfloats)
+
+
+def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split=False, bank=None):
     """Weight gradient of a (grouped) conv into the [tap][O][I] fp32 slabs ``Gs`` (+=).  k x k bf16 layers -- and fp32 layers in
     split-bf16 mode (the router trunks) -- take the atomic-free kernel (csrc/wgrad6.hip) with a cached workspace; everything else
     the general kernel."""
@@ -288,6 +328,13 @@ def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws
         dtc = F32S if split else _dt(x)
         kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
                                              ctypes.cast(_int_array(kws), ctypes.c_void_p), dtc)
+        if kib > 0 and bank is not None and W6_DEFER and PROFILE is None:
+            # weight-bank layer: the partial slabs stay in the arena, the bank sums all layers' partials in one batched launch
+            ws = _w6_arena_take(x.device, 2 * kib * 256)
+            if ws is not None:
+                if call("hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc, 1) == 0:
+                    bank.defer_w6(list(Gs), seg, ws, [G, N, H, W, I, O, dtc, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
+                    return
         if kib > 0:
             key = (x.device, torch.cuda.current_stream().stream_id)       # branches on different streams run concurrently
             ws = _w6_ws.get(key)
@@ -296,7 +343,7 @@ def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws
                 _w6_ws[key] = ws
             if split:
                 info = dict(info, dtype="split_bf16")
-            if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc) == 0:
+            if _timed("conv_wgrad", info, "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc, 0) == 0:
                 return
     _timed("conv_wgrad", info, "hdmoe_conv_wgrad", x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, 1, 1 if ones else 0, khs, kws, pts, pts, _dt(x))
 
@@ -381,7 +428,8 @@ class _MPConvFn(torch.autograd.Function):
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w and ctx.ent is not None:
             # bank path: accumulate into the bank's slab; one multi-tensor launch at the end of backward finishes every gradient
-            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split)
+            _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split,
+                   bank=ctx.bank)
             ctx.bank.note_backward(ctx.ent)
         elif need_w:
             sizes = [khs[g] * kws[g] * O * I for g in range(G)]

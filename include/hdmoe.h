@@ -72,7 +72,11 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
 int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, int dtype);
 int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin,
                       int Cout, const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, int dtype,
-                      HS stream);
+                      int defer, HS stream);
+/* defer != 0: the partial slabs stay in `ws` (2 x ws_kib KiB: one region per kernel-size class) and are summed into G later by ONE
+ * batched launch per 16 (layer, class) items.  Per deferred call i: G + 8 i = its per-expert slabs, seg[i], ws[i], and
+ * dims + 16 i = {ngroups, N, H, W, Cin, Cout, dtype, 0, kh[0..7]}. */
+int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, HS stream);
 
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
  * (tag << 56 | s_memtime) of every later launch; NULL switches it off (tools/conv6_check.py --stamps). */
