@@ -300,6 +300,9 @@ def main():
             args.no_graph = True
         buckets.enabled = True
         if graphed is not None:
+            if hasattr(graphed, "after") and world > 1:          # staged step: a branch's bucket goes to RCCL as soon as its backward is launched
+                graphed.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
+
             def step():
                 l = graphed()
                 buckets.finish()

@@ -38,7 +38,13 @@ def note_forked_streams(streams) -> None:
 
 
 DEFER_FINISH = False
+STAGE = None                                              # name of the running backward section (graph.Stager)
 PENDING: list = []
+
+
+def finish_stage(stage: str) -> None:
+    for b in PENDING:
+        b.finish_stage(stage)
 
 
 def finish_pending() -> None:
@@ -55,7 +61,7 @@ def join_forked_streams() -> None:
 
 class Entry:
     __slots__ = ("params", "dtype", "gain", "alpha", "normalize", "O", "I", "khs", "kws", "Ipad", "Opad", "wstride", "wdstride",
-                 "gsizes", "wf", "wd", "G", "ready", "used_bwd")
+                 "gsizes", "wf", "wd", "G", "ready", "used_bwd", "bwd_stage", "rows", "done")
 
     def __init__(self, params, dtype, gain, alpha, normalize):
         self.params = tuple(params)
@@ -171,11 +177,13 @@ class WeightBank:
                 d["mutate_ok"], d["gain"], d["out_scale"] = 1, ent.gain, ent.alpha
                 rows.extend((di, o) for o in range(ent.O))
                 di += 1
+            ent.rows = rows[-G * ent.O:]                     # this entry's (descriptor, output row) pairs
             ent.ready = True
         self._descs = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)
         self._rows = torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).contiguous().to(self.device)
         self._nrows = len(rows)
         self._built_ptrs = self._ptr_signature()
+        self._stage_rows = {}
 
     # ------------------------------------------------------------------------------------------------- per step
     def begin_step(self, training: bool):
@@ -197,11 +205,14 @@ class WeightBank:
         self._gflat.zero_()
         for e in self.entries.values():
             e.used_bwd = False
+            e.done = False
+            e.bwd_stage = None
         call("hdmoe_wbank_prep", self._descs, self._rows, self._nrows, 1 if training else 0)
 
     def note_backward(self, ent: Entry):
         ent.used_bwd = True
-        if DEFER_FINISH:                                  # staged backward (graph.Stager): finished once, after the last section
+        if DEFER_FINISH:                                  # staged backward (graph.Stager): finished section by section
+            ent.bwd_stage = STAGE
             if self not in PENDING:
                 PENDING.append(self)
             return
@@ -210,20 +221,52 @@ class WeightBank:
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
 
     def defer_w6(self, Gs, seg, ws, dims):
-        """A k x k layer left its partial weight-gradient slabs in `ws` (ops._wgrad): summed in _finish."""
-        self._w6_pending.append((Gs, seg, ws, dims))
+        """A k x k layer left its partial weight-gradient slabs in `ws` (ops._wgrad): summed in _finish / finish_stage."""
+        self._w6_pending.append((Gs, seg, ws, dims, STAGE if DEFER_FINISH else None))
+
+    def _reduce_w6(self, stage):
+        pend = [it for it in getattr(self, "_w6_pending", []) if stage is None or it[4] == stage]
+        if not pend:
+            return
+        self._w6_pending = [it for it in self._w6_pending if not (stage is None or it[4] == stage)]
+        Gflat, segs, wss, dims = [], [], [], []                # one launch per 16 (layer, kernel-size class) items
+        for Gs, seg, ws, d, _ in pend:
+            Gflat += list(Gs) + [None] * (8 - len(Gs))
+            segs.append(seg); wss.append(ws); dims += d
+        call("hdmoe_conv_wgrad6_reduce_batch", Gflat, segs, wss, dims, len(pend))
+
+    def finish_stage(self, stage: str):
+        """Staged backward: the weight gradients of the entries whose backward ran in section ``stage`` -- their parameters' .grad are
+        final afterwards, so that section's gradient bucket can go to RCCL while later sections still run."""
+        ents = [e for e in self.entries.values() if e.ready and e.used_bwd and not e.done and e.bwd_stage == stage]
+        self._reduce_w6(stage)
+        if not ents:
+            return
+        key = (stage, tuple(id(e) for e in ents))
+        rows = self._stage_rows.get(key)
+        if rows is None:                                     # built in the eager warm-up steps; static afterwards
+            flat = [r for e in ents for r in e.rows]
+            rows = self._stage_rows[key] = torch.tensor(flat, dtype=torch.int32).reshape(-1, 2).contiguous().to(self.device)
+        call("hdmoe_wbank_bwd", self._descs, rows, rows.shape[0])
+        for e in ents:
+            e.done = True
 
     def _finish(self):
-        """Runs once at the end of the backward pass: all weight gradients in one launch."""
+        """Runs once at the end of the backward pass: all (remaining) weight gradients in one launch."""
         self._cb_queued = False
         join_forked_streams()
-        pend, self._w6_pending = getattr(self, "_w6_pending", []), []
-        if pend:                                           # deferred wgrad6 reductions: one launch per 16 (layer, kernel-size class) items
-            Gflat, segs, wss, dims = [], [], [], []
-            for Gs, seg, ws, d in pend:
-                Gflat += list(Gs) + [None] * (8 - len(Gs))
-                segs.append(seg); wss.append(ws); dims += d
-            call("hdmoe_conv_wgrad6_reduce_batch", Gflat, segs, wss, dims, len(pend))
+        self._reduce_w6(None)
+        ents = [e for e in self.entries.values() if e.ready]
+        if any(e.done for e in ents):                        # some sections were finished on their own: only the rest
+            rest = [e for e in ents if not e.done]
+            if rest:
+                key = ("rest", tuple(id(e) for e in rest))
+                rows = self._stage_rows.get(key)
+                if rows is None:
+                    flat = [r for e in rest for r in e.rows]
+                    rows = self._stage_rows[key] = torch.tensor(flat, dtype=torch.int32).reshape(-1, 2).contiguous().to(self.device)
+                call("hdmoe_wbank_bwd", self._descs, rows, rows.shape[0])
+            return
         call("hdmoe_wbank_bwd", self._descs, self._rows, self._nrows)
 
 

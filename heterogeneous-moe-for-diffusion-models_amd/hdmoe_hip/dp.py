@@ -1,10 +1,21 @@
 """Data-parallel gradient exchange for the HDMOEM replicas: one process per GPU, flat fp32 gradient buckets whose
-views ARE the parameters' ``.grad`` tensors, one RCCL all-reduce(avg) per bucket over xGMI launched from autograd hooks
-as soon as the bucket's last gradient lands (overlaps the rest of backward).
+views ARE the parameters' ``.grad`` tensors, one RCCL all-reduce(avg) per bucket over xGMI.
 
 Sample routing is per-sample and every expert is replicated, so the path has no data-path collective: the only exchange
 is this gradient all-reduce.  An expert that received no sample on a rank contributes exact
 zeros (its bucket slice was memset and never written) so every rank reduces identical layouts.
+
+When do the collectives go out?  Almost every gradient of this path is written straight into its bucket view by a kernel (the
+weight bank's finish launch, the norm / bias / table backward kernels) and never passes through an AccumulateGrad node, so
+autograd hooks cannot tell when a bucket is complete.  Completion is known structurally instead:
+  * default (multi-stream step): the parameters are bucketed by the SECTION of the staged step (hdmoe_hip/graph.py) whose backward
+    finishes them -- "vit" (ViT router + experts), "unet" (U-Net router + experts), "rest" (stem, fusion, head, preconditioning).
+    ``launch_tag("vit")`` / ``launch_tag("unet")`` are called by StagedStep right after the section's backward graph has been
+    launched, on that section's stream: the all-reduce then runs beside the remaining sections.  ``finish()`` sends what is left
+    and waits.  Without a StagedStep everything goes out from ``finish()`` (correct, not overlapped).
+  * HDMOE_SIDE_STREAMS=0 (one stream): 16 MB buckets in reverse registration order; hooks launch the complete prefix for the few
+    gradients that do come through autograd, the rest again from ``finish()``.
+The order of collectives is the same on every rank by construction (tags in a fixed order / bucket index order).
 """
 from __future__ import annotations
 
@@ -15,25 +26,45 @@ import torch.distributed as dist
 
 
 class GradBuckets:
+    TAGS = ("vit", "unet", "rest")
+
+    @staticmethod
+    def tag_of(name: str) -> str:
+        """Section of the staged step that completes the parameter's gradient (HDMOEM attribute names, models/_assembly.py)."""
+        if ".vit_router." in "." + name or ".VIT_experts." in "." + name:
+            return "vit"
+        if ".Unet_router." in "." + name or ".Unet_experts." in "." + name:
+            return "unet"
+        return "rest"
+
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()                                           # backward produces gradients roughly in this order
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        named.reverse()                                            # backward produces gradients roughly in this order
         from . import ops as _ops
-        # with side streams every bucket goes out from finish() anyway (see `eager` below): one flat bucket = one collective
-        cap = int(bucket_mb * (1 << 20) / 4) if not _ops.SIDE_STREAMS else (1 << 62)
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
-        cur, n = [], 0
-        for p in params:
-            if cur and n + p.numel() > cap:
+        self.tags: List[str] = []
+        if _ops.SIDE_STREAMS:
+            # one flat bucket per section of the staged step (sections complete as a whole: see the module docstring)
+            for tag in self.TAGS:
+                members = [p for n, p in named if self.tag_of(n) == tag]
+                if members:
+                    self._seal(members, sum(p.numel() for p in members))
+                    self.tags.append(tag)
+        else:
+            cap = int(bucket_mb * (1 << 20) / 4)
+            cur, n = [], 0
+            for _, p in named:
+                if cur and n + p.numel() > cap:
+                    self._seal(cur, n)
+                    cur, n = [], 0
+                cur.append(p)
+                n += p.numel()
+            if cur:
                 self._seal(cur, n)
-                cur, n = [], 0
-            cur.append(p)
-            n += p.numel()
-        if cur:
-            self._seal(cur, n)
+            self.tags = ["-"] * len(self.buckets)
         self._pending = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
         self._next = 0                                             # collectives are issued strictly in bucket order
@@ -79,8 +110,19 @@ class GradBuckets:
         else:                                                       # gloo (CPU tests): no AVG
             self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def launch_tag(self, tag: str):
+        """The section ``tag`` of the staged step has been launched on the current stream: send its bucket.  Collectives are issued
+        strictly in bucket order on every rank, so an earlier bucket that is still waiting goes first (it is complete as well:
+        sections are launched in bucket order)."""
+        if not self.enabled or tag not in self.tags:
+            return
+        bi = self.tags.index(tag)
+        while self._next <= bi:
+            self._launch(self._next)
+            self._next += 1
+
     def finish(self):
-        """Call after backward: reduce buckets whose hooks did not all fire (unused experts), wait for all."""
+        """Call after backward: reduce every bucket that has not gone out yet, wait for all."""
         while self._next < len(self.buckets):
             self._launch(self._next)
             self._next += 1

@@ -112,22 +112,27 @@ class Stager:
     def _section(self, stage: str, producer: str):
         self.end()
         self.begin(stage)
+        bank.STAGE = stage
         pairs = [(t, d.grad) for t, d in self.cuts[producer] if d.grad is not None]
         if pairs:
             torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+        if stage != "pre_bwd":
+            bank.finish_stage(stage)                              # this section's weight gradients are final when its graph ends
 
     def backward(self, loss):
         if "post" not in self.order:
             raise RuntimeError("staged step: the model did not reach its stage boundaries (not the banked HDMOEM path)")
         bank.DEFER_FINISH = True
         try:
+            bank.STAGE = "post"
             loss.backward()                                       # fusion + head + loss section; stops at the detached leaves
             self._section("unet_bwd", "unet")
             self._section("vit_bwd", "vit")
             self._section("pre_bwd", "pre")
         finally:
             bank.DEFER_FINISH = False
-        bank.finish_pending()                                     # every weight gradient: one launch, in the last section
+            bank.STAGE = None
+        bank.finish_pending()                                     # the remaining weight gradients (stem, fusion, head): last section
 
 
 _ACTIVE = None
@@ -168,6 +173,7 @@ class StagedStep:
             raise RuntimeError(f"staged step: unexpected stage sequence {st.order}")
         self.graphs = st.graphs
         self._keep = st                                           # boundary tensors live in the graphs' pools
+        self.after = {}                                           # {"unet_bwd" | "vit_bwd": callable}: run on that section's stream right after its launch
 
     def _run(self, step_fn, capture: bool):
         global _ACTIVE
@@ -200,6 +206,12 @@ class StagedStep:
                 if ev is not None:
                     ev[name][1].record(stream)
 
+        def done(name, stream):                                   # e.g. hand the section's gradient bucket to RCCL (dp.GradBuckets.launch_tag)
+            fn = self.after.get(name)
+            if fn is not None:
+                with torch.cuda.stream(stream):
+                    fn()
+
         main.wait_stream(cur)
         run("pre", main)
         u.wait_stream(main); v.wait_stream(main)
@@ -210,6 +222,8 @@ class StagedStep:
         u.wait_stream(main); v.wait_stream(main)
         run("unet_bwd", u)
         run("vit_bwd", v)
+        done("vit_bwd", v)
+        done("unet_bwd", u)
         main.wait_stream(u); main.wait_stream(v)
         run("pre_bwd", main)
         cur.wait_stream(main)

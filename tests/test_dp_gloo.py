@@ -120,8 +120,13 @@ def _hdmoem_worker(rank, world, port, q, side_streams):
     names = [n for n, _ in model.named_parameters()]
     buckets = GradBuckets(model, bucket_mb=0.25)
     assert buckets.nbytes() == 4 * sum(p.numel() for p in model.parameters())
-    if side_streams:
-        assert len(buckets.buckets) == 1 and not buckets.eager
+    if side_streams:                                                 # one bucket per section of the staged step
+        assert buckets.tags == ["vit", "unet", "rest"] and not buckets.eager
+        for tag, members in zip(buckets.tags, buckets._members):
+            owned = {id(p) for p in members}
+            assert all((id(p) in owned) == (GradBuckets.tag_of(n) == tag) for n, p in model.named_parameters())
+        assert GradBuckets.tag_of("net.VIT_experts.0.patch.weight") == "vit" and GradBuckets.tag_of("net.Unet_router.linear.weights") == "unet"
+        assert GradBuckets.tag_of("net.input_proj.weights") == "rest" and GradBuckets.tag_of("log_var_linear.weights") == "rest"
     else:
         assert len(buckets.buckets) >= 3 and buckets.eager
     # every parameter's .grad is a view into exactly one bucket, in reverse registration order
@@ -142,6 +147,10 @@ def _hdmoem_worker(rank, world, port, q, side_streams):
             p.grad.add_(mine[n])                                     # AccumulateGrad into the bucket view
             for h in p._post_accumulate_grad_hooks.values():         # what autograd calls after accumulating
                 h(p)
+        if side_streams:                                             # what StagedStep does after launching the two branch backwards
+            buckets.launch_tag("vit")
+            buckets.launch_tag("unet")
+            assert buckets._next == 2
         buckets.finish()
         # reference: average of both ranks' synthetic gradients
         for n, p in model.named_parameters():

@@ -1,0 +1,114 @@
+"""Two ranks on ONE MI355X (gloo over CUDA tensors: the box has a single GPU, RCCL needs one device per rank): the default training
+configuration -- staged hipGraph step, a branch's gradient bucket handed to the process group right after that branch's backward
+graph is launched, the rest from finish() -- against the single-process average of the two ranks' gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "heterogeneous-moe-for-diffusion-models_amd")
+    for p in (pkg, os.path.join(pkg, "Utils"), root):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hdmoe_hip
+    from hdmoe_hip import ops, graph as hgraph
+    from hdmoe_hip.dp import GradBuckets
+    from Utils import configs
+    from Utils.utils import EDM_LOSS
+    from models import model_config1
+    from oracle.recipe import fill_state, make_inputs
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    hdmoe_hip.set_compute_dtype(torch.float32)
+    kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
+    crit = EDM_LOSS(num_experts=4, sigma_data=0.5, Unet_bal=0.05, vit_bal=0.1, z_bal=0.005, prior_bal=0.0)
+
+    def build():
+        m = model_config1.preconditioned_HDMOEM(**kw)
+        m.load_state_dict(fill_state(m.state_dict(), 5))
+        return m.to(dev).eval()
+
+    def inputs(r):
+        return {k: v.to(dev) for k, v in make_inputs(6, 4, 32, 4, 77, 768, 20 + r).items()}
+
+    def step_fn(model, inp, zero):
+        def f():
+            zero()
+            out = model(x=inp["x"], sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["unet_mask"],
+                        Vit_router_mask=inp["vit_mask"], zeta=0.0, return_log_var=True)
+            loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+            hgraph.backward(loss["loss"])
+            return loss["loss"].detach()
+        return f
+
+    # single-process reference: both ranks' batches through one replica, gradients averaged (plain eager, one stream)
+    saved = ops.SIDE_STREAMS
+    ops.SIDE_STREAMS = False
+    ref_model = build()
+    acc = {}
+    for r in range(world):
+        f = step_fn(ref_model, inputs(r), lambda: ref_model.zero_grad(set_to_none=False))
+        f(); f()                                                   # second pass runs through the weight bank
+        torch.cuda.synchronize()
+        for n, p in ref_model.named_parameters():
+            if p.grad is not None:
+                acc[n] = acc.get(n, 0) + p.grad.detach().clone() / world
+    ops.SIDE_STREAMS = saved
+    del ref_model
+
+    model = build()
+    buckets = GradBuckets(model)
+    assert buckets.tags == ["vit", "unet", "rest"]
+    staged = hgraph.StagedStep(step_fn(model, inputs(rank), buckets.zero_grad), dev, warmup=2)
+    staged.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
+    for _ in range(2):
+        staged()
+        assert buckets._next == 2                                  # the two branch buckets went out before finish()
+        buckets.finish()
+    torch.cuda.synchronize()
+    bad = []
+    for n, p in model.named_parameters():
+        if n in acc:
+            scale = float(acc[n].abs().max())
+            err = float((p.grad - acc[n]).abs().max())
+            if err > 3e-4 * scale + 1e-7:
+                bad.append((n, err, scale))
+    q.put((rank, bad[:5], len(acc)))
+    dist.destroy_process_group()
+
+
+def test_staged_step_with_bucket_overlap_two_ranks_on_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, bad, n in got:
+        assert not bad, (rank, bad)
+        assert n > 400
