@@ -1398,6 +1398,9 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
       const int OBP = (OT == 2 && esz == 2) ? 96 : 32 * OT;
       const size_t lds = (size_t)esz * (PTpx * OBP + (gm.TH + kh[g] - 1) * (gm.TW + kw[g] - 1) * WG2_IB);
       if (lds > 64 * 1024 || mt > 13) ok = false;
+      // the kernel decodes halo pixels with (px * magic) >> 20, exact only while px * HWp < 2^20 (px < HHp * HWp)
+      const long HWp = gm.TW + kw[g] - 1, HHp = gm.TH + kh[g] - 1;
+      if (HHp * HWp * HWp >= (1l << 20)) ok = false;
     }
     if (ok) {
       for (int g = 0; g < ngroups; ++g) {

@@ -453,7 +453,7 @@ class _MPConvFn(torch.autograd.Function):
 F32S = 2                                  # C-ABI dtype code: fp32 tensors, split-bf16 arithmetic (include/hdmoe.h HDMOE_F32S)
 # The fp32 router trunks run on the bf16 matrix pipe as split-bf16 (3 MFMAs per product, ~1e-5 relative): HDMOE_ROUTER_SPLIT=0
 # keeps them on the fp32-input MFMA kernels.
-ROUTER_SPLIT = _os.environ.get("HDMOE_ROUTER_SPLIT", "1") != "0"
+ROUTER_SPLIT = _os.environ.get("HDMOE_ROUTER_SPLIT", "1") != "0" and _os.environ.get("HDMOE_CONV6", "1") != "0"   # (the split kernels are conv6's)
 
 
 def _split_ok(x4: Tensor, ws, ones: bool) -> bool:

@@ -90,6 +90,13 @@ def _sqrt_scalar(ss: torch.Tensor) -> torch.Tensor:
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    """AdamW over all parameters in two launches (global-norm clip + update), ``torch.optim.AdamW``'s state_dict layout.
+
+    Semantics where it differs from the reference loop (Utils/training.py:55-65,195-197): bias correction uses ONE step counter for all
+    tensors (torch keeps one per tensor; identical whenever every tensor receives a gradient from step 1, which the flat gradient
+    buckets guarantee: a never-routed expert's gradient is an exact zero, not None), so an expert that got no sample in a step
+    still sees weight decay and moment decay in that step -- the DDP-like behaviour of gradient-as-bucket-view training, whereas the
+    reference's `if not mask.any(): continue` leaves its grad None and AdamW skips it."""
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) > 8:
@@ -98,6 +105,17 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW needs the same betas/eps in every group (lr and weight_decay may differ)")
         self._table = None
         self._step = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the gradients IN PLACE.  torch's default (set_to_none=True) would detach the flat DP bucket views / the weight bank's
+        gradient buffers that the backward kernels accumulate into (the all-reduce would then run on stale buffers), so it is
+        only honoured when asked for explicitly."""
+        if set_to_none:
+            return super().zero_grad(set_to_none=True)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad.zero_()
 
     def _ensure_state(self):
         ents = []
