@@ -41,7 +41,7 @@ struct W6Args {
 // a product is three MFMAs, dy_hi x_hi + dy_hi x_lo + dy_lo x_hi -- see conv6s.hip.  LDS then holds a hi and a lo plane of each
 // tile (single-buffered: the next tile waits in registers, loaded beside the current tile's loop).
 template <int KS, int TWS, int OT, bool SPLIT>
-__global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
+DEVI void wgrad6_body(const W6Args& a, const int zslot) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TW = 1 << TWS, TH = 256 >> TWS, HWp = TW + KS - 1, HHp = TH + KS - 1, NTAPS = KS * KS;
   constexpr int HP16 = (HWp * HHp + 15) / 16;               // x halo pieces (16 pixels x 64 B)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
   const int q4 = (lane & 15) >> 2, col4 = (lane & 16) + 4 * (lane & 3);
   const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32 * OT;
   // partition slot blockIdx.z -> (expert of this class, pixel partition): experts take ceil(units / upw) consecutive slots each
-  int gi = 0, chunk = blockIdx.z, row0 = 0, units = 0;
+  int gi = 0, chunk = zslot, row0 = 0, units = 0;
   for (; gi < a.ngr; ++gi) {
     const int g = a.groups[gi];
     row0 = a.seg ? a.seg[g] : 0;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
   }
   }
   // ---- partial slab [tap][Cout][Cin] of this (expert, pixel partition): plain stores, 128-byte runs
-  float* P = a.ws + (long)blockIdx.z * a.ws_item;
+  float* P = a.ws + (long)zslot * a.ws_item;
   const int col = lane & 31;
   auto store_tile = [&](const f32x16& v, int tap, int ob) {
 #pragma unroll
@@ -289,6 +289,19 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
     for (int t = 0; t < OT; ++t) store_tile(acc[s][t], wave + 8 * s, t);
   if (extra_ok) store_tile(acce, etap, eob);
 #endif
+}
+
+template <int KS, int TWS, int OT, bool SPLIT>
+__global__ __launch_bounds__(512) void wgrad6_kernel(W6Args a) {
+  wgrad6_body<KS, TWS, OT, SPLIT>(a, blockIdx.z);
+}
+// Both kernel-size classes of a layer (3x3 experts and 5x5 experts) in ONE launch: partition slots [0, a3.chunks) run the 3x3 program,
+// the rest the 5x5 program.  As two launches the 3x3 class -- a third of the 5x5 class's FLOPs but latency-bound, hence just as long
+// -- ran in front of the 5x5 class; side by side it disappears under it.
+template <int TWS, int OT>
+__global__ __launch_bounds__(512) void wgrad6_dual_kernel(W6Args a3, W6Args a5) {
+  if ((int)blockIdx.z < a3.chunks) wgrad6_body<3, TWS, OT, false>(a3, blockIdx.z);
+  else wgrad6_body<5, TWS, OT, false>(a5, blockIdx.z - a3.chunks);
 }
 
 // G[g][e] += sum over the non-empty partitions c of ws[gi][c][e]   (fixed order: deterministic)
@@ -443,6 +456,36 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
   const long units_l = (long)N * a.tpi;
   bool done[HDMOE_MAX_GROUPS] = {false};
   int cls = 0;
+  static const bool dual_ok = !(getenv("HDMOE_W6_DUAL") && atoi(getenv("HDMOE_W6_DUAL")) == 0);
+  bool has3 = false, has5 = false;
+  for (int g = 0; g < ngroups; ++g) { has3 = has3 || kh[g] == 3; has5 = has5 || kh[g] == 5; }
+  if (dual_ok && defer && has3 && has5 && dtype == HDMOE_BF16) {
+    W6Args c[2];
+    for (int k = 0; k < 2; ++k) {
+      const int ks = k == 0 ? 3 : 5;
+      c[k] = a;
+      c[k].ngr = 0;
+      for (int g = 0; g < ngroups; ++g) if (kh[g] == ks) { c[k].groups[c[k].ngr++] = g; c[k].pt = pt[g]; c[k].pl = pl[g]; }
+      c[k].ws_item = (long)ks * ks * Cout * Cin;
+      int upw, slots;
+      w6_partition(units_l, c[k].ngr, ngroups, ibs, obs, upw, slots);
+      c[k].upw = upw; c[k].chunks = slots;
+    }
+    // workspace regions in the order the classes appear in the group list (what hdmoe_conv_wgrad6_reduce_batch assumes)
+    const int firstk = kh[0] == 3 ? 0 : 1;
+    c[firstk].ws = (float*)ws; c[1 - firstk].ws = (float*)((char*)ws + need1);
+    const dim3 grid(ibs, obs, c[0].chunks + c[1].chunks);
+#define W6_DUAL(T, O)                                                                                                              \
+    do {                                                                                                                           \
+      constexpr int TW_ = 1 << T, TH_ = 256 >> T, HP16_ = ((TW_ + 4) * (TH_ + 4) + 15) / 16;                                        \
+      const size_t lds_ = 2 * (size_t)(HP16_ * 1024 + 16 * O * 1024);                                                              \
+      static bool attr_ = false;                                                                                                   \
+      if (!attr_) { attr_ = true; (void)hipFuncSetAttribute((const void*)wgrad6_dual_kernel<T, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+      hipLaunchKernelGGL((wgrad6_dual_kernel<T, O>), grid, dim3(512), lds_, stream, c[0], c[1]);                                   \
+    } while (0)
+    if (TWS == 5) { if (OT == 2) W6_DUAL(5, 2); else W6_DUAL(5, 1); } else { if (OT == 2) W6_DUAL(4, 2); else W6_DUAL(4, 1); }
+    return hdmoe_launch_status();
+  }
   for (int g = 0; g < ngroups; ++g) {
     if (done[g]) continue;
     a.ngr = 0;

@@ -1031,6 +1031,34 @@ def test_graph_replay_with_side_streams_matches_single_stream_eager():
     assert len(ref) > 400
 
 
+def test_weight_bank_path_matches_first_step_bf16(golden_wide):
+    """From the second step on every conv weight goes through the weight bank: deferred, batched wgrad6 reductions, both kernel-size
+    classes of a layer in one launch, per-section finish.  Same inputs, eval mode: the bank-path gradients must equal the
+    first-step gradients (plain per-layer path, itself pinned to the reference by test_full_model_real_widths)."""
+    import hdmoe_hip
+    from conftest import wide_setup
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    try:
+        variant, model, kw, state, inp = wide_setup(golden_wide)
+        model = load_into(model, state).eval()
+        grads = []
+        for it in range(3):
+            model.zero_grad(set_to_none=False)
+            x = dev(inp["x"])
+            out = model(x=x, sigma=dev(inp["sigma"]), text_emb=dev(inp["text"]), Unet_router_mask=dev(inp["unet_mask"]),
+                        Vit_router_mask=dev(inp["vit_mask"]), zeta=0.0, return_log_var=True, **golden_wide["extra"])
+            out["denoised"].float().square().mean().backward()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        assert all(e.ready for e in model._hdmoe_bank.entries.values())
+        gmax = max(float(v.abs().max()) for v in grads[0].values())
+        for n, g0 in grads[0].items():
+            for later in grads[1:]:
+                close_scaled(later[n], g0, 2e-3, msg=n, atol=2e-4 * gmax)
+    finally:
+        hdmoe_hip.set_compute_dtype(torch.float32)
+
+
 def test_staged_step_matches_plain_backward():
     """hdmoe_hip/graph.py StagedStep: seven hipGraphs (stem / U-Net branch / ViT branch / fusion+loss+their backward / the two
     branch backwards / stem backward), autograd cut at the stage boundaries with detached leaves, the branches replayed on two
