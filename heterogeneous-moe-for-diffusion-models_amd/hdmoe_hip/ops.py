@@ -283,10 +283,10 @@ def fanout(x: Tensor, n: int):
 class _W6Arena:
     """Workspace of the DEFERRED wgrad6 reductions: every k x k layer of the weight bank keeps its partial slabs until the end of the
     backward pass, where one batched launch per 16 layers sums them (WeightBank._finish).  One bump-allocated buffer per device,
-    rewound at the start of a step; HDMOE_W6_ARENA_MB (default 4096) of the 288 GB."""
+    rewound at the start of a step; HDMOE_W6_ARENA_MB (default 8192) of the 288 GB."""
 
     def __init__(self, device):
-        mb = int(_os.environ.get("HDMOE_W6_ARENA_MB", "4096"))
+        mb = int(_os.environ.get("HDMOE_W6_ARENA_MB", "8192"))
         self.buf = torch.empty(mb << 18, dtype=torch.float32, device=device)
         self.off = 0
 

@@ -1031,6 +1031,95 @@ def test_graph_replay_with_side_streams_matches_single_stream_eager():
     assert len(ref) > 400
 
 
+@pytest.mark.parametrize("dtype,rel", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("M,HW,I,O,groups", [(512, 1, 64, 32, 4), (512, 1, 768, 64, 4), (37, 64, 32, 128, 3), (1, 5000, 96, 32, 1),
+                                              (700, 16, 2048, 32, 1), (9, 1024, 64, 96, 2)])
+def test_pointwise_wgrad_kernels_vs_torch(dtype, rel, M, HW, I, O, groups):
+    """csrc/lwgrad.hip (weight gradient of linear / 1x1 layers; bf16 through wave-private LDS, fp32 straight from row loads) through the
+    public op against torch autograd, grouped with ragged segments including an EMPTY expert, plus the matching input gradient."""
+    import hdmoe_hip
+    from hdmoe_hip import ops
+    torch.manual_seed(11)
+    x = torch.randn(M, HW, I, device=DEV).to(dtype)
+    ws = [torch.nn.Parameter(torch.randn(O, I, device=DEV) / I ** 0.5) for _ in range(groups)]
+    cuts = sorted(torch.randint(0, M + 1, (groups - 1,)).tolist()) if groups > 1 else []
+    if groups > 2:
+        cuts[1] = cuts[0]                                               # expert 1 gets no row
+    seg = [0] + cuts + [M]
+    segd = torch.tensor(seg, dtype=torch.int32, device=DEV) if groups > 1 else None
+    xd = x.clone().requires_grad_(True)
+    y = ops.mp_conv(xd, ws if groups > 1 else ws[0], 1.0, seg=segd, normalize=False)
+    go = torch.randn_like(y.float()).to(dtype)
+    y.backward(go)
+    xr = x.float().requires_grad_(True)
+    wr = [w.detach().to(dtype).float().requires_grad_(True) for w in ws]      # the kernels see weights rounded to the compute dtype
+    yr = torch.cat([xr[seg[g]:seg[g + 1]] @ wr[g].t() for g in range(groups)])        # normalize=False: the weight is used as it is
+    (yr * go.float()).sum().backward()
+    close_scaled(y, yr, rel, msg="y")
+    close_scaled(xd.grad, xr.grad, rel, msg="dx")
+    gmax = max(float(w.grad.abs().max()) for w in wr if w.grad is not None)
+    for g in range(groups):
+        close_scaled(ws[g].grad, wr[g].grad, rel, msg=f"dw[{g}]", atol=rel * 0.05 * gmax)
+        if seg[g + 1] == seg[g]:
+            assert float(ws[g].grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,O,res", [(2048, 8192, 32, False), (8192, 2048, 32, True), (100, 1024, 64, True), (33, 4096, 32, False)])
+def test_long_contraction_pointwise_kernel_vs_torch(M, K, O, res):
+    """csrc/kgemm.hip (1x1 forward / dgrad with K >= 1024 and few outputs: patch embedding, un-patching input gradient)."""
+    import hdmoe_hip
+    from hdmoe_hip import ops
+    torch.manual_seed(3)
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    w = torch.nn.Parameter(torch.randn(O, K, device=DEV) / K ** 0.5)
+    r = torch.randn(M, O, device=DEV).bfloat16() if res else None
+    y = ops.mp_conv(x, w, 1.0, res=r, alpha=0.8 if res else 1.0, beta=0.6 if res else 0.0, normalize=False)
+    yr = (0.8 if res else 1.0) * (x.float() @ w.detach().bfloat16().float().t()) + (0.6 * r.float() if res else 0.0)
+    close_scaled(y, yr, 1e-2, msg="y")
+    assert torch.equal(y, ops.mp_conv(x, w, 1.0, res=r, alpha=0.8 if res else 1.0, beta=0.6 if res else 0.0, normalize=False))   # fixed-order reduction
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,p,C", [(32, 4, 32), (32, 16, 32), (16, 8, 8), (8, 2, 4)])
+def test_patch_relayout_and_fanout_sum(dtype, H, p, C):
+    """Vectorised patch relayout (both token orders, both directions) against torch reshapes; patch embedding as relayout + linear
+    against F.conv2d(stride = p); the n-way gradient sum of ops.fanout."""
+    import torch.nn.functional as F
+    from hdmoe_hip import ops
+    from hdmoe_hip._lib import call, dtype_code
+    torch.manual_seed(5)
+    N, hp = 3, H // p
+    img = torch.randn(N, H, H, C, device=DEV).to(dtype)
+    for order in (0, 1):
+        tok = torch.empty(N, hp, hp, C * p * p, dtype=dtype, device=DEV)
+        call("hdmoe_patch_relayout", tok, img, N, H, H, C, p, hp, hp, order, 0, dtype_code(dtype))
+        t6 = img.reshape(N, hp, p, hp, p, C).permute(0, 1, 3, 2, 4, 5)                  # (n, ph, pw, i, j, c)
+        ref = t6.reshape(N, hp, hp, -1) if order == 0 else t6.permute(0, 1, 2, 5, 3, 4).reshape(N, hp, hp, -1)
+        assert torch.equal(tok, ref), order
+        back = torch.empty_like(img)
+        call("hdmoe_patch_relayout", back, tok, N, H, H, C, p, hp, hp, order, 1, dtype_code(dtype))
+        assert torch.equal(back, img), order
+    E = 16
+    w = torch.nn.Parameter(torch.randn(E, C, p, p, device=DEV) / (C * p * p) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(E, device=DEV))
+    xi = img.clone().requires_grad_(True)
+    y = ops.patch_embed(xi, w, b)
+    go = torch.randn_like(y.float()).to(dtype)
+    y.backward(go)
+    xr = img.float().requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride=p).permute(0, 2, 3, 1).reshape(N, hp * hp, E)
+    (yr * go.float()).sum().backward()
+    rel = 2e-5 if dtype == torch.float32 else 2e-2
+    close_scaled(y, yr, rel, msg="patch y"); close_scaled(xi.grad, xr.grad, rel, msg="patch dx")
+    close_scaled(w.grad, wr.grad, rel, msg="patch dw"); close_scaled(b.grad, br.grad, rel, msg="patch db")
+    t = torch.randn(5, 7, C, device=DEV).to(dtype).requires_grad_(True)
+    parts = ops.fanout(t, 5)
+    sum(((k + 1.0) * parts[k].float()).sum() for k in (0, 1, 3, 4)).backward()          # one alias unused
+    close_scaled(t.grad, torch.full_like(t.float(), 1.0 + 2.0 + 4.0 + 5.0), 1e-6 if dtype == torch.float32 else 1e-2, msg="fanout")
+
+
 def test_weight_bank_path_matches_first_step_bf16(golden_wide):
     """From the second step on every conv weight goes through the weight bank: deferred, batched wgrad6 reductions, both kernel-size
     classes of a layer in one launch, per-section finish.  Same inputs, eval mode: the bank-path gradients must equal the

@@ -3,7 +3,8 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
+qsel = sys.argv[4] if len(sys.argv) > 4 else None
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if qsel is None or r.get("Queue_Id") == qsel or "seed_advance" in r["Kernel_Name"]))
 marks = [s for s, e, k in ev if "seed_advance" in k][-n - 1:]
 t0, t1 = marks[0], marks[-1]
 agg = collections.defaultdict(lambda: [0, 0])
