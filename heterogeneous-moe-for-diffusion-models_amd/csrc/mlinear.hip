@@ -1,0 +1,155 @@
+// Many small linear layers that read the SAME input in one launch: the per-block conditioning projections.
+//   Unet_block.emb_layer  (reference models/model_components.py:232-236: emb = 1 + emb_layer(embedding) * gain) -- 14 blocks, and
+//   MP_Attention.q_time / k_time / v_time (reference models/model_internals.py:360-372)            -- 3 per ViT block,
+// each a (rows x 64) x (64 x 32..128) product per expert: 2-8 MFLOP that cost a launch (+ a dependent-launch gap on the critical
+// path) for the forward, the input gradient and the weight gradient of EVERY layer.  Here all L layers of a bank go out together:
+//   y_l[r][o]  = c + sum_i x[r][i] * W_l,g(r)[o][i]          (W = the weight bank's prepared fp32 image: normalised, gain folded in)
+//   dx[r][i]   = sum_l sum_o dy_l[r][o] * W_l,g(r)[o][i]     (also the sum over the layers that autograd would do with L - 1 adds)
+//   dW_l,g[o][i] += sum_{r in g} dy_l[r][o] * x[r][i]        (one owner thread per element: no atomics, deterministic)
+// fp32 FMA code on purpose: the whole family is ~100 MFLOP per step and lives on the fp32 vector path.
+#include "common.h"
+#include "hdmoe.h"
+
+namespace {
+
+constexpr int ML_MAXL = 16;                // the argument block has to stay under the 4 KB kernarg limit
+struct MLArgs {
+  const float* x; const int* seg;
+  const float* w[ML_MAXL];     // layer image: [ngroups][O][Ipad]
+  float* y[ML_MAXL];           // forward: outputs; wgrad: unused
+  const float* dy[ML_MAXL];
+  float* G[ML_MAXL][HDMOE_MAX_GROUPS];
+  int O[ML_MAXL];
+  int L, R, I, Ipad, ngroups;
+  float c;
+};
+DEVI int ml_group(const MLArgs& a, int r) {
+  if (!a.seg) return 0;
+  int g = -1;
+  for (int k = 0; k < a.ngroups; ++k)
+    if (r >= a.seg[k] && r < a.seg[k + 1]) g = k;
+  return g;
+}
+
+// grid (row, layer); thread = output channel
+__global__ __launch_bounds__(128) void mlin_fwd_kernel(MLArgs a) {
+  extern __shared__ float sx[];
+  const int r = blockIdx.x, l = blockIdx.y, O = a.O[l];
+  for (int i = threadIdx.x; i < a.I; i += blockDim.x) sx[i] = a.x[(long)r * a.I + i];
+  __syncthreads();
+  const int g = ml_group(a, r);
+  for (int o = threadIdx.x; o < O; o += blockDim.x) {
+    float acc = 0.f;
+    if (g >= 0) {
+      const float* wr = a.w[l] + ((long)g * O + o) * a.Ipad;
+      for (int i = 0; i < a.I; ++i) acc += sx[i] * wr[i];
+      acc += a.c;
+    }
+    a.y[l][(long)r * O + o] = acc;
+  }
+}
+// grid (row); thread = input channel; walks all layers
+__global__ __launch_bounds__(128) void mlin_dgrad_kernel(MLArgs a, float* dx) {
+  extern __shared__ float sd[];
+  const int r = blockIdx.x;
+  const int g = ml_group(a, r);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                       // I <= 4 * blockDim.x
+  for (int l = 0; l < a.L; ++l) {
+    const int O = a.O[l];
+    __syncthreads();
+    for (int o = threadIdx.x; o < O; o += blockDim.x) sd[o] = a.dy[l][(long)r * O + o];
+    __syncthreads();
+    if (g < 0) continue;
+    const float* wl = a.w[l] + (long)g * O * a.Ipad;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      if (i < a.I) {
+        float s = 0.f;
+        for (int o = 0; o < O; ++o) s += sd[o] * wl[(long)o * a.Ipad + i];
+        acc[k] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < a.I) dx[(long)r * a.I + i] = acc[k];
+  }
+}
+// grid (o-tile of 4 rows, layer, group); thread = input channel i (x4 output rows per block); walks the group's rows
+__global__ __launch_bounds__(256) void mlin_wgrad_kernel(MLArgs a) {
+  const int l = blockIdx.y, g = blockIdx.z, O = a.O[l];
+  const int o0 = blockIdx.x * 4;
+  if (o0 >= O || !a.G[l][g]) return;
+  const int r0 = a.seg ? a.seg[g] : 0, r1 = a.seg ? a.seg[g + 1] : a.R;
+  for (int i = threadIdx.x; i < a.I; i += blockDim.x) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+      const float xv = a.x[(long)r * a.I + i];
+      const float* d = a.dy[l] + (long)r * O + o0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (o0 + k < O) acc[k] += d[k] * xv;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (o0 + k < O) a.G[l][g][(long)(o0 + k) * a.I + i] += acc[k];
+  }
+}
+
+static bool ml_fill(MLArgs& a, const void* x, const int* seg, const float* const* w, const int* O, int L, int R, int I, int Ipad, int ngroups) {
+  if (!x || !w || !O || L < 1 || L > ML_MAXL || R < 0 || I < 1 || I > 512 || Ipad < I || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return false;
+  a.x = (const float*)x; a.seg = seg; a.L = L; a.R = R; a.I = I; a.Ipad = Ipad; a.ngroups = ngroups; a.c = 0.f;
+  for (int l = 0; l < ML_MAXL; ++l) {
+    a.w[l] = l < L ? w[l] : nullptr; a.O[l] = l < L ? O[l] : 0; a.y[l] = nullptr; a.dy[l] = nullptr;
+    for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) a.G[l][g] = nullptr;
+    if (l < L && (!w[l] || O[l] < 1)) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* y[l] [R][O[l]] = c + x [R][I] . w[l][g(r)]^T   for l < L layers sharing the input; w[l] = prepared fp32 image [ngroups][O[l]][Ipad];
+ * lens = host array O[0..L) ; seg: device row offsets or NULL (one group) */
+int hdmoe_mlinear_fwd(float* const* y, const float* x, const float* const* w, const int* seg, const int* lens, int L, int R, int I,
+                      int Ipad, int ngroups, float c, hipStream_t stream) {
+  MLArgs a;
+  if (!y || !ml_fill(a, x, seg, w, lens, L, R, I, Ipad, ngroups)) return HDMOE_EINVAL;
+  for (int l = 0; l < L; ++l) { if (!y[l]) return HDMOE_EINVAL; a.y[l] = y[l]; }
+  a.c = c;
+  if (R == 0) return HDMOE_OK;
+  hipLaunchKernelGGL(mlin_fwd_kernel, dim3(R, L), dim3(128), I * sizeof(float), stream, a);
+  return hdmoe_launch_status();
+}
+/* dx [R][I] = sum_l dy[l] [R][O[l]] . w[l][g(r)] */
+int hdmoe_mlinear_dgrad(float* dx, const float* const* dy, const float* const* w, const int* seg, const int* lens, int L, int R, int I,
+                        int Ipad, int ngroups, hipStream_t stream) {
+  MLArgs a;
+  if (!dx || !dy || !ml_fill(a, dx, seg, w, lens, L, R, I, Ipad, ngroups)) return HDMOE_EINVAL;
+  int maxO = 0;
+  for (int l = 0; l < L; ++l) { if (!dy[l]) return HDMOE_EINVAL; a.dy[l] = dy[l]; if (lens[l] > maxO) maxO = lens[l]; }
+  if (R == 0) return HDMOE_OK;
+  hipLaunchKernelGGL(mlin_dgrad_kernel, dim3(R), dim3(128), maxO * sizeof(float), stream, a, dx);
+  return hdmoe_launch_status();
+}
+/* G[l * 8 + g] [O[l]][I] += sum over the rows of group g of dy[l]^T . x    (G: host array of L * 8 device pointers, NULL = skip) */
+int hdmoe_mlinear_wgrad(float* const* G, const float* const* dy, const float* x, const int* seg, const int* lens, int L, int R, int I,
+                        int ngroups, hipStream_t stream) {
+  MLArgs a;
+  const float* dummy[ML_MAXL];
+  for (int l = 0; l < ML_MAXL; ++l) dummy[l] = x;
+  if (!G || !dy || !ml_fill(a, x, seg, dummy, lens, L, R, I, I, ngroups)) return HDMOE_EINVAL;
+  int maxO = 0;
+  for (int l = 0; l < L; ++l) {
+    if (!dy[l]) return HDMOE_EINVAL;
+    a.dy[l] = dy[l]; if (lens[l] > maxO) maxO = lens[l];
+    for (int g = 0; g < ngroups; ++g) a.G[l][g] = G[l * HDMOE_MAX_GROUPS + g];
+  }
+  if (R == 0) return HDMOE_OK;
+  hipLaunchKernelGGL(mlin_wgrad_kernel, dim3((maxO + 3) / 4, L, ngroups), dim3(I < 256 ? ((I + 63) / 64 * 64) : 256), 0, stream, a);
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

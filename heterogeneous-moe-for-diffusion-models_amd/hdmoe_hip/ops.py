@@ -504,6 +504,64 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
     return y.reshape(*shape[:-1], y.shape[-1])
 
 
+class _MultiLinearFn(torch.autograd.Function):
+    """L linear layers over the same fp32 input in one launch each for forward / input gradient / weight gradient
+    (csrc/mlinear.hip).  ``tensors`` = L * G weights (layer-major); every layer must be a ready weight-bank entry."""
+
+    @staticmethod
+    def forward(ctx, x, seg, ents, bank, c, *tensors):
+        x = _f32(x)
+        R, I = x.shape
+        L = len(ents)
+        G = len(ents[0].params)
+        Os = [e.O for e in ents]
+        ys = [torch.empty((R, o), dtype=torch.float32, device=x.device) for o in Os]
+        call("hdmoe_mlinear_fwd", ys, x, [e.wf for e in ents], seg, Os, L, R, I, ents[0].Ipad, G, c)
+        ctx.save_for_backward(x, seg)
+        ctx.meta = (ents, bank, Os, G)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, seg = ctx.saved_tensors
+        ents, bank, Os, G = ctx.meta
+        R, I = x.shape
+        L = len(ents)
+        gs = [_f32(g) if g is not None else _zeros((R, o), torch.float32, x.device) for g, o in zip(gs, Os)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("hdmoe_mlinear_dgrad", dx, gs, [e.wf for e in ents], seg, Os, L, R, I, ents[0].Ipad, G)
+        if any(ctx.needs_input_grad[5:]):
+            Gs = []
+            for e in ents:
+                Gs += list(e.G) + [None] * (8 - G)
+            call("hdmoe_mlinear_wgrad", Gs, gs, x, seg, Os, L, R, I, G)
+            for e in ents:
+                bank.note_backward(e)
+        return (dx, None, None, None, None) + (None,) * (L * G)
+
+
+def multi_linear(x: Tensor, layers, gain: float, *, seg: Optional[Tensor] = None, c: float = 0.0, training: bool = False):
+    """[c + mp_linear_l(x) for l in layers] for MP_Conv layers (kernel ()) that all read ``x`` (R, I) fp32; ``layers`` = list of per-layer
+    weight lists (one weight per expert with ``seg``).  One launch for all layers once the weight bank has their images; the plain
+    per-layer path otherwise (first steps, no bank, more than 16 layers)."""
+    L = len(layers)
+    bank = _bank.ACTIVE
+    ents = None
+    if bank is not None and 1 <= L <= 16 and x.ndim == 2 and x.dtype == torch.float32 and MULTI_LINEAR:
+        ents = [bank.lookup(ws, torch.float32, float(gain), 1.0, True) for ws in layers]
+        ok = all(e is not None for e in ents) and len({(e.I, e.Ipad, len(e.params)) for e in ents if e is not None}) == 1
+        if ok and all(e.khs == [1] * len(e.params) for e in ents) and (seg is not None or len(ents[0].params) == 1):
+            flat = [w for ws in layers for w in ws]
+            return list(_MultiLinearFn.apply(x, seg, ents, bank, float(c), *flat))
+    outs = [mp_conv(x, ws if seg is not None else ws[0], gain, seg=seg, training=training) for ws in layers]
+    return [affine(o, 1.0, c) for o in outs] if c != 0.0 else outs
+
+
+MULTI_LINEAR = _os.environ.get("HDMOE_MULTI_LINEAR", "1") != "0"
+
+
 class _PatchLinearFn(torch.autograd.Function):
     """Vit_expert.patch when the image divides into patches (model_components.py:670-679): a stride-p p x p conv is a linear layer on
     the patch vectors, so: one relayout pass (image -> tokens of C*p*p features in the weight's own (c, i, j) order, the parameter

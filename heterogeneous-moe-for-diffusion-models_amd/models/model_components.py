@@ -112,15 +112,16 @@ def _w(mods: Sequence[nn.Module], path: str) -> List[Tensor]:
     return out
 
 
-def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding: Tensor, seg: Optional[Tensor]) -> Tensor:
-    """Unet_block.forward (reference model_components.py:232-253) over a bank of same-shaped blocks."""
+def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding: Tensor, seg: Optional[Tensor], film: Optional[Tensor] = None) -> Tensor:
+    """Unet_block.forward (reference model_components.py:232-253) over a bank of same-shaped blocks.
+    ``film``: the block's 1 + emb_layer(embedding) * gain when the caller computed it for all blocks at once (ops.multi_linear)."""
     b0 = blocks[0]
     tr = b0.training
 
     def conv(name, inp, gain=1.0, **kw):
         return ops.mp_conv(inp, [getattr(b, name).weights for b in blocks], gain, seg=seg, training=tr, **kw)
 
-    emb = ops.affine(conv("emb_layer", embedding, b0.emb_gain), 1.0, 1.0)           # 1 + emb_layer(e) * gain
+    emb = film if film is not None else ops.affine(conv("emb_layer", embedding, b0.emb_gain), 1.0, 1.0)   # 1 + emb_layer(e) * gain
     x = ops.resample(x, b0.resample)
     t = b0.residual_balance
     n = ((1.0 - t) ** 2 + t ** 2) ** 0.5
@@ -185,22 +186,32 @@ def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_e
             text_emb = ops.seq_mean(text_emb)
         emb = ops.mp_sum(emb, conv([e.map_text for e in experts], text_emb), e0.label_balance)
     emb = ops.mp_silu(emb)
-    nblk = sum("conv" not in n for n in e0.encoders.keys()) + len(e0.decoders)
-    embs = list(ops.fanout(emb, nblk))                          # every block's emb_layer reads it: ONE gradient sum instead of nblk - 1 adds
+    # every block's FiLM vector 1 + emb_layer(emb) * gain depends on emb only: all blocks in ONE launch (and one launch each for the
+    # input and weight gradients) instead of a linear + an affine per block
+    blk = [[e.encoders[n] for e in experts] for n in e0.encoders.keys() if "conv" not in n] + [[e.decoders[n] for e in experts] for n in e0.decoders.keys()]
+    if len({b[0].emb_gain for b in blk}) == 1 and len(blk) <= 16:
+        films = ops.multi_linear(emb, [[b.emb_layer.weights for b in bs] for bs in blk], blk[0][0].emb_gain, seg=seg, c=1.0, training=tr)
+        embs = [None] * len(blk)
+    else:
+        films = [None] * len(blk)
+        embs = list(ops.fanout(emb, len(blk)))                  # ONE gradient sum instead of nblk - 1 adds
     skips = []
+    bi = 0
     for name in e0.encoders.keys():
         mods = [e.encoders[name] for e in experts]
         if "conv" in name:
             x = conv(mods, x, ones=True)                         # torch.cat([x, ones]) folded into the conv (:416)
         else:
-            x = unet_block_bank_forward(mods, x, embs.pop(), seg)
+            x = unet_block_bank_forward(mods, x, embs[bi], seg, films[bi])
+            bi += 1
         x, sk = ops.fanout(x, 2)
         skips.append(sk)
     for name in e0.decoders.keys():
         mods = [e.decoders[name] for e in experts]
         if "block" in name:
             x = ops.mp_cat(x, skips.pop(), e0.concat_balance)
-        x = unet_block_bank_forward(mods, x, embs.pop(), seg)
+        x = unet_block_bank_forward(mods, x, embs[bi], seg, films[bi])
+        bi += 1
     return conv([e.out_conv for e in experts], x, [e.out_gain for e in experts])
 
 
@@ -386,7 +397,7 @@ def vit_bank_compatible(experts: Sequence[nn.Module], H: int, W: int) -> bool:
     return True
 
 
-def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t: Optional[Tensor], rag) -> Tensor:
+def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t, rag, tproj=None) -> Tensor:
     """Vit_block.forward (reference model_components.py:520-562) over a bank of blocks; tok (R, Sp, C) ragged rows, t (R, T)."""
     b0 = blocks[0]
     tr = b0.training
@@ -410,7 +421,9 @@ def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t: Option
     q = lin([a.q_proj for a in at], yq, b0.gain_s)
     k = lin([a.k_proj for a in at], yk, b0.gain_s)
     v = lin([a.v_proj for a in at], yv, b0.gain_s)
-    if a0.time_dependent and t is not None:
+    if tproj is not None:                                         # q_time / k_time / v_time of all blocks were computed in one launch
+        q, k, v = ops.seq_bcast_add(q, tproj[0]), ops.seq_bcast_add(k, tproj[1]), ops.seq_bcast_add(v, tproj[2])
+    elif a0.time_dependent and t is not None:
         tq, tk, tv = t if isinstance(t, (list, tuple)) else ops.fanout(t, 3)
         q = ops.seq_bcast_add(q, lin([a.q_time for a in at], tq, b0.gain_t))
         k = ops.seq_bcast_add(k, lin([a.k_time for a in at], tk, b0.gain_t))
@@ -449,9 +462,17 @@ def vit_expert_bank_forward(experts: Sequence["Vit_expert"], x: Tensor, time_emb
             tx = ops.mp_conv(tx, [e.map_txt.weights for e in experts], seg=seg, training=tr)
         t = ops.mp_sum(t, tx, e0.emb_balance)
     nb = len(e0.diffit)
-    ts = list(ops.fanout(t, 3 * nb)) if (t is not None and e0.diffit[0].TMSA.time_dependent) else None
+    timed = t is not None and e0.diffit[0].TMSA.time_dependent
+    tps = ts = None
+    if timed and 3 * nb <= 16 and len({b.gain_t for b in e0.diffit}) == 1:
+        # the time projections of every block depend on t only: 3 * nb linear layers in one launch
+        layers = [[getattr(e.diffit[i].TMSA, nm).weights for e in experts] for i in range(nb) for nm in ("q_time", "k_time", "v_time")]
+        tps = ops.multi_linear(t, layers, e0.diffit[0].gain_t, seg=seg, training=tr)
+    elif timed:
+        ts = list(ops.fanout(t, 3 * nb))
     for i in range(nb):
-        tok = vit_block_bank_forward([e.diffit[i] for e in experts], tok, t if ts is None else ts[3 * i:3 * i + 3], rag)
+        tok = vit_block_bank_forward([e.diffit[i] for e in experts], tok, t if ts is None else ts[3 * i:3 * i + 3], rag,
+                                     None if tps is None else tps[3 * i:3 * i + 3])
     tok = ops.ln_rag(tok, [e.norm.weight for e in experts], [e.norm.bias for e in experts], rag, e0.norm.eps)
     outs = []
     for e, p, part in zip(experts, ps, ops.rag_unpack(tok, rag)):

@@ -213,6 +213,17 @@ int hdmoe_attn_rag_bwd(void* dq, void* dk, void* dv, float* const* dbias, float*
                        const void* q, const void* k, const void* v, const float* lse, const float* const* bias, const int* seg,
                        const int* lens, const int* sb, int ngroups, int R, int Sp, int H, int D, int dtype, HS stream);
 
+/* ---- many small linear layers over ONE input in one launch (csrc/mlinear.hip): Unet_block.emb_layer of every block
+ * (model_components.py:232-236) and MP_Attention.q_time / k_time / v_time of every ViT block (model_internals.py:360-372).
+ * w[l] = prepared fp32 weight image of layer l, [ngroups][O[l]][Ipad]; lens = host array O[0..L); y / dy: host arrays of L device
+ * pointers to [R][O[l]] fp32; G: host array of L * 8 device pointers to the [O[l]][I] fp32 gradient slabs (NULL = skip), += */
+int hdmoe_mlinear_fwd(float* const* y, const float* x, const float* const* w, const int* seg, const int* lens, int L, int R, int I,
+                      int Ipad, int ngroups, float c, HS stream);
+int hdmoe_mlinear_dgrad(float* dx, const float* const* dy, const float* const* w, const int* seg, const int* lens, int L, int R,
+                        int I, int Ipad, int ngroups, HS stream);
+int hdmoe_mlinear_wgrad(float* const* G, const float* const* dy, const float* x, const int* seg, const int* lens, int L, int R, int I,
+                        int ngroups, HS stream);
+
 /* ---- K1/K2: router head + dispatch  (model_components.py:155-168, model_config1.py:11-39) ---------------------- */
 int hdmoe_router_head_fwd(float* sparse, float* probs, float* xout, int* idx, const float* logits, const float* noise,
                           const float* mask, long B, int E, int k, HS stream);
