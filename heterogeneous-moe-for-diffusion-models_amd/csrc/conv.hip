@@ -1363,6 +1363,11 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     if (kh[s] * kw[s] > maxtaps) maxtaps = kh[s] * kw[s];
   }
   a.tap_lo = 0;
+  if (stride == 1 && !ones && ngroups == 1 && !seg && Ho == H && Wo == W && kh[0] == kw[0] && maxtaps > 1 && maxtaps * Cin <= 64 &&
+      pt[0] == (kh[0] - 1) / 2 && pl[0] == (kw[0] - 1) / 2) {
+    const int rc = swg_try_launch(x, dy, G[0], N, H, W, Cin, Cout, kh[0], pt[0], pl[0], dtype, stream);
+    if (rc <= 0) return rc;
+  }
   if (stride == 1 && !ones && maxtaps == 1 && Ho == H && Wo == W) {
     bool plain = true;
     for (int g = 0; g < ngroups; ++g) plain = plain && kh[g] == 1 && kw[g] == 1 && pt[g] == 0 && pl[g] == 0;

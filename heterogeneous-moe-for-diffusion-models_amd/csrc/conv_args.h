@@ -40,3 +40,7 @@ int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* se
 
 // Pointwise forward / dgrad with Cin >= 1024 and Cout <= 64 (kgemm.hip).  Same return convention.
 int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+
+// k x k fp32 weight gradient for tiny input channel counts (taps * Cin <= 64: the stem), one expert (lwgrad.hip).  Same return convention.
+int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
+                   hipStream_t stream);

@@ -178,7 +178,88 @@ __global__ __launch_bounds__(256) void lwg_f32_kernel(LwgArgs a) {
   lwg_flush<OT, IT>(acc, reinterpret_cast<float*>(lds), a.G[g], o0, i0, a.I, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k x k layers with a TINY input channel count (the stem: 4 latent channels -> 32, 3x3; reference model_config2.py:66-68 input_proj):
+// taps * Cin <= 64 columns.  The tiled kernel pads Cin to 32 per tap (8x the work, 300 us); here the contraction over pixels runs on
+// v_mfma_f32_32x32x2_f32 with A = dy[pixel][o] (a coalesced row load) and B = the im2col row of x built on the fly
+// (column n = tap * Cin + i -> x[pixel + tap offset][i], zero outside the image): 2 MFMAs per 2 pixels per wave, HBM-bound on dy.
+struct SwgArgs { const float* x; const float* dy; float* G; int N, H, W, Cin, Cout, k, pt, pl; long ppb; };
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void swg_f32_kernel(SwgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][NBLK][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int o0 = blockIdx.y * 32;
+  const long total = (long)a.N * a.H * a.W;
+  const long p0 = (long)blockIdx.x * a.ppb, p1 = p0 + a.ppb < total ? p0 + a.ppb : total;
+  const int ncols = a.k * a.k * a.Cin;
+  int ky[NBLK], kx[NBLK], ci[NBLK]; bool colok[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int n = 32 * b + r;
+    colok[b] = n < ncols;
+    const int tap = colok[b] ? n / a.Cin : 0;
+    ci[b] = colok[b] ? n - tap * a.Cin : 0;
+    ky[b] = tap / a.k - a.pt; kx[b] = tap % a.k - a.pl;
+  }
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) acc[b] = (f32x16)(0.f);
+  for (long pb = p0 + 2 * wave; pb < p1; pb += 8) {
+    const long p = pb + h;
+    const bool ok = p < p1;
+    const long pc = ok ? p : p0;
+    const int xw = (int)(pc % a.W);
+    const long t = pc / a.W;
+    const int yh = (int)(t % a.H);
+    const long img = t / a.H;
+    const float dv = ok ? a.dy[pc * a.Cout + o0 + r] : 0.f;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int yy = yh + ky[b], xx = xw + kx[b];
+      const bool in = ok && colok[b] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const float xv = in ? a.x[((img * a.H + yy) * a.W + xx) * a.Cin + ci[b]] : 0.f;
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, xv, acc[b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[((wave * NBLK + b) * 16 + reg) * 64 + lane] = acc[b][reg];
+  __syncthreads();
+  for (int e = tid; e < NBLK * 1024; e += 256) {
+    const int l = e & 63, reg = (e >> 6) & 15, b = e >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * NBLK + b) * 16 + reg) * 64 + l];
+    const int o = o0 + acc_row(reg, l), n = 32 * b + (l & 31);
+    if (n < ncols) {
+      const int tap = n / a.Cin, i = n - tap * a.Cin;
+      atomicAdd(&a.G[((long)tap * a.Cout + o) * a.Cin + i], v);
+    }
+  }
+}
+
 }  // namespace
+
+// k x k fp32 layer with taps * Cin <= 64 (one expert, stride 1, "same" geometry): G [tap][Cout][Cin] += .  Same return convention.
+int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
+                   hipStream_t stream) {
+  static const bool off = getenv("HDMOE_SWG") && atoi(getenv("HDMOE_SWG")) == 0;
+  if (off || dtype != HDMOE_F32 || Cout % 32 || k * k * Cin > 64 || !x || !dy || !G) return 1;
+  SwgArgs a;
+  a.x = (const float*)x; a.dy = (const float*)dy; a.G = G; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.pt = pt; a.pl = pl;
+  const long total = (long)N * H * W;
+  long blocks = 512 / (Cout / 32); if (blocks < 1) blocks = 1;
+  long ppb = (total + blocks - 1) / blocks; ppb = (ppb + 7) / 8 * 8; if (ppb < 64) ppb = 64;
+  a.ppb = ppb;
+  const dim3 grid((unsigned)((total + ppb - 1) / ppb), Cout / 32);
+  const int NBLK = (k * k * Cin + 31) / 32;
+  if (NBLK == 1) hipLaunchKernelGGL(swg_f32_kernel<1>, grid, dim3(256), 4 * 1 * 4096, stream, a);
+  else hipLaunchKernelGGL(swg_f32_kernel<2>, grid, dim3(256), 4 * 2 * 4096, stream, a);
+  return hdmoe_launch_status();
+}
 
 // Returns HDMOE_OK after launching, a negative status on a launch error, or 1 when the layer is outside this file's domain.
 int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, long HW, int Cin, int Cout,
