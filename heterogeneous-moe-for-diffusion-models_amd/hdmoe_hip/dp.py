@@ -74,9 +74,10 @@ class GradBuckets:
         # whole step runs on one stream; otherwise every bucket goes out in finish(), after autograd has joined the streams.
         self.eager = not _ops.SIDE_STREAMS
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
-        for bi, members in enumerate(self._members):
-            for p in members:
-                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        if self.eager:                                             # (a hook keeps the parameter's AccumulateGrad node -- and the stream it was
+            for bi, members in enumerate(self._members):           #  created on -- alive across steps; the section mode needs none)
+                for p in members:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
     def _seal(self, members, n):
         p0 = members[0]

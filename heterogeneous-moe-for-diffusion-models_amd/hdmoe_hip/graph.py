@@ -12,6 +12,14 @@ import torch
 from . import bank, ops
 
 
+def _capture_mode() -> str:
+    """Error mode of the stream captures.  With a process group alive (RCCL's watchdog thread polls events from its own thread)
+    a 'global' capture would turn that polling into a capture error; 'thread_local' restricts the check to the capturing thread.
+    The step allocates nothing new after its warm-up runs, so the laxer mode hides nothing."""
+    import torch.distributed as dist
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 class GraphedStep:
     def __init__(self, step_fn, device, warmup: int = 3):
         """``step_fn()`` must be re-runnable with static inputs and write its results into persistent tensors."""
@@ -25,7 +33,7 @@ class GraphedStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             ops.advance_seed(self.device)
             self.out = step_fn()
             bank.join_forked_streams()                  # every forked side stream is back on the capture stream
@@ -79,7 +87,7 @@ class Stager:
         if self.capture:
             g = torch.cuda.CUDAGraph()
             self.graphs[name] = g
-            self._ctx = torch.cuda.graph(g, pool=self.pools[self.KIND[name]], stream=st)
+            self._ctx = torch.cuda.graph(g, pool=self.pools[self.KIND[name]], stream=st, capture_error_mode=_capture_mode())
         else:
             for other in self.streams.values():                  # warm-up: plain streams, fully ordered
                 st.wait_stream(other)

@@ -145,7 +145,7 @@ def _hdmoem_worker(rank, world, port, q, side_streams):
                 continue
             mine[n] = torch.randn(p.shape, generator=g)
             p.grad.add_(mine[n])                                     # AccumulateGrad into the bucket view
-            for h in p._post_accumulate_grad_hooks.values():         # what autograd calls after accumulating
+            for h in (p._post_accumulate_grad_hooks or {}).values():  # what autograd calls after accumulating (hooks exist in the one-stream mode only)
                 h(p)
         if side_streams:                                             # what StagedStep does after launching the two branch backwards
             buckets.launch_tag("vit")
