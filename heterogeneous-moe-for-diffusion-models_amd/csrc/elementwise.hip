@@ -486,6 +486,18 @@ __global__ void mp_silu_bwd_vec_kernel(T* dx, const T* dy, const T* x, long nv) 
     vstore<T>(dx + v * W, f);
   }
 }
+// dx = gx + dy * silu'(x): the gradient of a tensor that feeds mp_silu AND a second consumer (residual / skip), in one pass
+template <typename T>
+__global__ void mp_silu_bwd_add_vec_kernel(T* dx, const T* dy, const T* x, const T* gx, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(v, nv) {
+    float f[W], g[W], r[W];
+    vload<T>(f, x + v * W); vload<T>(g, dy + v * W); vload<T>(r, gx + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = r[j] + g[j] * mp_silu_grad_f(f[j]);
+    vstore<T>(dx + v * W, f);
+  }
+}
 template <typename T>
 __global__ void film_silu_fwd_vec_kernel(T* out, const T* u, const float* e, long HW, int C, long nv, uint32_t seed_lo, uint32_t seed_hi,
                                          const unsigned long long* seed_dev, float p) {
@@ -592,6 +604,49 @@ __global__ void cat2_bwd_vec_kernel(T* da, T* db, const T* dout, float wa, float
     const float wgt = first ? wa : wb;
 #pragma unroll
     for (int j = 0; j < W; ++j) f[j] *= wgt;
+    vstore<T>(first ? da + (r * cva + c) * W : db + (r * (cv - cva) + c - cva) * W, f);
+  }
+}
+// mp_cat + mp_silu of the result in one pass (decoder blocks: the concatenation feeds mp_silu and the skip / residual path), and the
+// matching backward: d(cat) = g_cat + g_h * silu'(cat), split and weighted
+template <typename T>
+__global__ void cat2_silu_fwd_vec_kernel(T* out, T* out_h, const T* a, const T* b, float wa, float wb, int Ca, int Cb, long rows) {
+  constexpr int W = VT<T>::W;
+  const int cva = Ca / W, cv = (Ca + Cb) / W;
+  GRID_STRIDE(v, rows * cv) {
+    const long r = v / cv; const int c = (int)(v - r * cv);
+    float f[W];
+    const bool first = c < cva;
+    vload<T>(f, first ? a + (r * cva + c) * W : b + (r * (cv - cva) + c - cva) * W);
+    const float wgt = first ? wa : wb;
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] *= wgt;
+    vstore<T>(out + v * W, f);
+    T tmp[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) tmp[j] = from_f<T>(f[j]);         // mp_silu sees the stored (rounded) value, like the two-kernel form
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = mp_silu_f(to_f(tmp[j]));
+    vstore<T>(out_h + v * W, f);
+  }
+}
+template <typename T>
+__global__ void cat2_silu_bwd_vec_kernel(T* da, T* db, const T* gcat, const T* gh, const T* xcat, float wa, float wb, int Ca, int Cb, long rows) {
+  constexpr int W = VT<T>::W;
+  const int cva = Ca / W, cv = (Ca + Cb) / W;
+  GRID_STRIDE(v, rows * cv) {
+    const long r = v / cv; const int c = (int)(v - r * cv);
+    float f[W], g[W], x[W];
+    vload<T>(g, gh + v * W); vload<T>(x, xcat + v * W);
+    if (gcat) vload<T>(f, gcat + v * W);
+    else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) f[j] = 0.f;
+    }
+    const bool first = c < cva;
+    const float wgt = first ? wa : wb;
+#pragma unroll
+    for (int j = 0; j < W; ++j) f[j] = (f[j] + g[j] * mp_silu_grad_f(x[j])) * wgt;
     vstore<T>(first ? da + (r * cva + c) * W : db + (r * (cv - cva) + c - cva) * W, f);
   }
 }
@@ -797,6 +852,28 @@ int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, hipStream_t s
 int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(dx) && al16(dy) && al16(x)) L1D(mp_silu_bwd_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, n / VT<T>::W);
                    else L1D(mp_silu_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)x, n))
+}
+/* dx = gx + dy * mp_silu'(x); 16-byte aligned, n % (16 / esz) == 0 */
+int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, long n, int dtype, hipStream_t stream) {
+  if (!dx || !dy || !x || !gx || !(al16(dx) && al16(dy) && al16(x) && al16(gx))) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0) L1D(mp_silu_bwd_add_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, (const T*)gx, n / VT<T>::W);
+                   else return HDMOE_EINVAL)
+}
+/* out = mp_cat(a, b) (weights wa, wb), out_h = mp_silu(out); Ca, Cb multiples of 16 / esz */
+int hdmoe_cat2_silu_fwd(void* out, void* out_h, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows, int dtype,
+                        hipStream_t stream) {
+  if (!(al16(out) && al16(out_h) && al16(a) && al16(b)) || !out || !out_h) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (Ca % VT<T>::W == 0 && Cb % VT<T>::W == 0)
+                     L1D(cat2_silu_fwd_vec_kernel<T>, rows * (Ca + Cb) / VT<T>::W, (T*)out, (T*)out_h, (const T*)a, (const T*)b, wa, wb, Ca, Cb, rows);
+                   else return HDMOE_EINVAL)
+}
+/* (da, db) = split((gcat + gh * mp_silu'(xcat)) * (wa | wb)); gcat may be NULL */
+int hdmoe_cat2_silu_bwd(void* da, void* db, const void* gcat, const void* gh, const void* xcat, float wa, float wb, int Ca, int Cb,
+                        long rows, int dtype, hipStream_t stream) {
+  if (!(al16(da) && al16(db) && al16(gcat) && al16(gh) && al16(xcat)) || !gh || !xcat) return HDMOE_EINVAL;
+  DT_SWITCH(dtype, if (Ca % VT<T>::W == 0 && Cb % VT<T>::W == 0)
+                     L1D(cat2_silu_bwd_vec_kernel<T>, rows * (Ca + Cb) / VT<T>::W, (T*)da, (T*)db, (const T*)gcat, (const T*)gh, (const T*)xcat, wa, wb, Ca, Cb, rows);
+                   else return HDMOE_EINVAL)
 }
 int hdmoe_sigmoid_fwd(void* out, const void* x, float a, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, L1D(sigmoid_fwd_kernel<T>, n, (T*)out, (const T*)x, a, n))

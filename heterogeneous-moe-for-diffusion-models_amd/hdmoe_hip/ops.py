@@ -919,6 +919,84 @@ def mp_cat(a: Tensor, b: Tensor, t: float = 0.5) -> Tensor:
     return _Cat2Fn.apply(a, b, c * (1.0 - t) / math.sqrt(na), c * t / math.sqrt(nb))
 
 
+class _SiluBranchFn(torch.autograd.Function):
+    """x -> (x, mp_silu(x)) for a tensor that feeds mp_silu and a second consumer (decoder-block input: skip / residual path).
+    Backward: ONE pass, dx = gx + gh * mp_silu'(x) (instead of mp_silu_bwd + a gradient-sum launch)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        h = torch.empty_like(x)
+        call("hdmoe_mp_silu_fwd", h, x, x.numel(), _dt(x))
+        ctx.save_for_backward(x)
+        return x.view(x.shape), h
+
+    @staticmethod
+    def backward(ctx, gx, gh):
+        (x,) = ctx.saved_tensors
+        if gh is None:
+            return gx
+        gh = _c(gh)
+        dx = torch.empty_like(x)
+        if gx is None:
+            call("hdmoe_mp_silu_bwd", dx, gh, x, x.numel(), _dt(x))
+        else:
+            call("hdmoe_mp_silu_bwd_add", dx, gh, x, _c(gx), x.numel(), _dt(x))
+        return dx
+
+
+class _CatSiluFn(torch.autograd.Function):
+    """(mp_cat(a, b), mp_silu(mp_cat(a, b))) in one pass; backward in one pass as well."""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        ctx.set_materialize_grads(False)
+        a = _c(a); b = _c(b)
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        out = torch.empty((*a.shape[:-1], Ca + Cb), dtype=a.dtype, device=a.device)
+        h = torch.empty_like(out)
+        call("hdmoe_cat2_silu_fwd", out, h, a, b, wa, wb, Ca, Cb, a.numel() // Ca, _dt(a))
+        ctx.save_for_backward(out)
+        ctx.meta = (wa, wb, a.shape, b.shape)
+        return out, h
+
+    @staticmethod
+    def backward(ctx, gcat, gh):
+        (out,) = ctx.saved_tensors
+        wa, wb, sa, sb = ctx.meta
+        da = torch.empty(sa, dtype=out.dtype, device=out.device)
+        db = torch.empty(sb, dtype=out.dtype, device=out.device)
+        if gh is None:
+            if gcat is None:
+                return None, None, None, None
+            call("hdmoe_cat2_bwd", da, db, _c(gcat), wa, wb, sa[-1], sb[-1], da.numel() // sa[-1], _dt(out))
+        else:
+            call("hdmoe_cat2_silu_bwd", da, db, None if gcat is None else _c(gcat), _c(gh), out, wa, wb, sa[-1], sb[-1], da.numel() // sa[-1], _dt(out))
+        return da, db, None, None
+
+
+def _vec_ok(*ts) -> bool:
+    return all(t.shape[-1] % (8 if t.dtype == torch.bfloat16 else 4) == 0 and t.dtype in (torch.bfloat16, torch.float32) for t in ts)
+
+
+def silu_branch(x: Tensor):
+    """(x, mp_silu(x)): the pair a decoder block needs (x continues on the skip / residual path)."""
+    if _vec_ok(x) and x.numel() % 8 == 0:
+        return _SiluBranchFn.apply(x)
+    x, xh = fanout(x, 2)
+    return x, mp_silu(xh)
+
+
+def mp_cat_silu(a: Tensor, b: Tensor, t: float = 0.5):
+    """(mp_cat(a, b, t), mp_silu of it) in one pass (model_internals.py:69-92 followed by :33-36)."""
+    if not (_vec_ok(a, b) and a.dtype == b.dtype):
+        return silu_branch(mp_cat(a, b, t))
+    na, nb = a.shape[-1], b.shape[-1]
+    c = math.sqrt((na + nb) / ((1.0 - t) ** 2 + t ** 2))
+    return _CatSiluFn.apply(a, b, c * (1.0 - t) / math.sqrt(na), c * t / math.sqrt(nb))
+
+
 class _ResampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mode):

@@ -112,7 +112,8 @@ def _w(mods: Sequence[nn.Module], path: str) -> List[Tensor]:
     return out
 
 
-def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding: Tensor, seg: Optional[Tensor], film: Optional[Tensor] = None) -> Tensor:
+def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding: Tensor, seg: Optional[Tensor], film: Optional[Tensor] = None,
+                            silu_x: Optional[Tensor] = None) -> Tensor:
     """Unet_block.forward (reference model_components.py:232-253) over a bank of same-shaped blocks.
     ``film``: the block's 1 + emb_layer(embedding) * gain when the caller computed it for all blocks at once (ops.multi_linear)."""
     b0 = blocks[0]
@@ -129,9 +130,10 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
         if b0.conv_skip is not None:
             x = conv("conv_skip", x)
         x, h = ops.pixel_norm_silu(x)
+    elif silu_x is not None:
+        h = silu_x                                             # the caller fused mp_silu into the producer of x (ops.mp_cat_silu)
     else:
-        x, xh = ops.fanout(x, 2)                               # main branch + skip / residual: one fused gradient sum
-        h = ops.mp_silu(xh)
+        x, h = ops.silu_branch(x)                              # main branch + skip / residual: one fused backward pass
     y = conv("conv_res1", h, b0.conv_gain1)
     y = ops.film_silu(y, emb, b0.dropout, tr)                 # FiLM * emb -> mp_silu -> F.dropout, one pass
     if b0.type == "dec" and b0.conv_skip is not None:
@@ -208,9 +210,13 @@ def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_e
         skips.append(sk)
     for name in e0.decoders.keys():
         mods = [e.decoders[name] for e in experts]
+        hx = None
         if "block" in name:
-            x = ops.mp_cat(x, skips.pop(), e0.concat_balance)
-        x = unet_block_bank_forward(mods, x, embs[bi], seg, films[bi])
+            if mods[0].resample == "keep":
+                x, hx = ops.mp_cat_silu(x, skips.pop(), e0.concat_balance)       # the concatenation and the block's mp_silu of it: one pass
+            else:
+                x = ops.mp_cat(x, skips.pop(), e0.concat_balance)
+        x = unet_block_bank_forward(mods, x, embs[bi], seg, films[bi], hx)
         bi += 1
     return conv([e.out_conv for e in experts], x, [e.out_gain for e in experts])
 

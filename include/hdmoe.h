@@ -97,6 +97,12 @@ int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, HS str
 int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
 int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, HS stream);
 int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, HS stream);
+/* fused decoder-block entry (model_components.py:232-253): the block input feeds mp_silu AND the skip / residual path */
+int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, long n, int dtype, HS stream);   /* dx = gx + dy * mp_silu'(x) */
+int hdmoe_cat2_silu_fwd(void* out, void* out_h, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows,
+                        int dtype, HS stream);                                                                     /* out = mp_cat, out_h = mp_silu(out) */
+int hdmoe_cat2_silu_bwd(void* da, void* db, const void* gcat, const void* gh, const void* xcat, float wa, float wb, int Ca,
+                        int Cb, long rows, int dtype, HS stream);
 int hdmoe_sigmoid_fwd(void* out, const void* x, float a, long n, int dtype, HS stream);                         /* sigmoid(a*x) */
 int hdmoe_sigmoid_bwd(void* dx, const void* dy, const void* y, float a, long n, int dtype, HS stream);
 int hdmoe_film_silu_fwd(void* out, const void* u, const float* e, int N, long HW, int C, int dtype, HS stream);  /* mp_silu(u * e[n][c]) */

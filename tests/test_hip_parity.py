@@ -1165,6 +1165,39 @@ def test_multi_linear_matches_the_per_layer_path(G, R, I, Os, four_d):
         close_scaled(a, b, 5e-6, msg=f"dw[{k}]", atol=1e-6 * gmax)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_silu_branch_and_cat_silu_match_the_separate_ops(dtype):
+    """ops.silu_branch / ops.mp_cat_silu (decoder-block entry: the block input feeds mp_silu and the skip / residual path) against
+    the separate mp_cat, mp_silu and gradient-sum ops they replace -- bit-identical forward, same backward."""
+    from hdmoe_hip import ops
+    torch.manual_seed(2)
+    a = torch.randn(5, 8, 8, 32, device=DEV).to(dtype)
+    b = torch.randn(5, 8, 8, 64, device=DEV).to(dtype)
+    g1 = torch.randn(5, 8, 8, 96, device=DEV).to(dtype)
+    g2 = torch.randn(5, 8, 8, 96, device=DEV).to(dtype)
+    a1, b1, a2, b2 = (t.clone().requires_grad_(True) for t in (a, b, a, b))
+    x1, h1 = ops.mp_cat_silu(a1, b1, 0.3)
+    xc = ops.mp_cat(a2, b2, 0.3)
+    x2, xh = ops.fanout(xc, 2)
+    h2 = ops.mp_silu(xh)
+    assert torch.equal(x1, x2) and torch.equal(h1, h2)
+    torch.autograd.backward([x1, h1], [g1, g2]); torch.autograd.backward([x2, h2], [g1, g2])
+    rel = 1e-6 if dtype == torch.float32 else 1e-2
+    close_scaled(a1.grad, a2.grad, rel, msg="da"); close_scaled(b1.grad, b2.grad, rel, msg="db")
+    for only_h in (False, True):
+        u1, u2 = a.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        p, q = ops.silu_branch(u1)
+        r, rh = ops.fanout(u2, 2)
+        s2 = ops.mp_silu(rh)
+        assert torch.equal(q, s2) and torch.equal(p, u1)
+        ga, gb = g1[..., :32].contiguous(), g2[..., :32].contiguous()
+        if only_h:
+            q.backward(gb); s2.backward(gb)
+        else:
+            torch.autograd.backward([p, q], [ga, gb]); torch.autograd.backward([r, s2], [ga, gb])
+        close_scaled(u1.grad, u2.grad, rel, msg="silu_branch")
+
+
 def test_weight_bank_path_matches_first_step_bf16(golden_wide):
     """From the second step on every conv weight goes through the weight bank: deferred, batched wgrad6 reductions, both kernel-size
     classes of a layer in one launch, per-section finish.  Same inputs, eval mode: the bank-path gradients must equal the
