@@ -488,13 +488,13 @@ __global__ void mp_silu_bwd_vec_kernel(T* dx, const T* dy, const T* x, long nv) 
 }
 // dx = gx + dy * silu'(x): the gradient of a tensor that feeds mp_silu AND a second consumer (residual / skip), in one pass
 template <typename T>
-__global__ void mp_silu_bwd_add_vec_kernel(T* dx, const T* dy, const T* x, const T* gx, long nv) {
+__global__ void mp_silu_bwd_add_vec_kernel(T* dx, const T* dy, const T* x, const T* gx, float sx, long nv) {
   constexpr int W = VT<T>::W;
   GRID_STRIDE(v, nv) {
     float f[W], g[W], r[W];
     vload<T>(f, x + v * W); vload<T>(g, dy + v * W); vload<T>(r, gx + v * W);
 #pragma unroll
-    for (int j = 0; j < W; ++j) f[j] = r[j] + g[j] * mp_silu_grad_f(f[j]);
+    for (int j = 0; j < W; ++j) f[j] = sx * r[j] + g[j] * mp_silu_grad_f(f[j]);
     vstore<T>(dx + v * W, f);
   }
 }
@@ -853,10 +853,10 @@ int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(dx) && al16(dy) && al16(x)) L1D(mp_silu_bwd_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, n / VT<T>::W);
                    else L1D(mp_silu_bwd_kernel<T>, n, (T*)dx, (const T*)dy, (const T*)x, n))
 }
-/* dx = gx + dy * mp_silu'(x); 16-byte aligned, n % (16 / esz) == 0 */
-int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, long n, int dtype, hipStream_t stream) {
+/* dx = sx * gx + dy * mp_silu'(x); 16-byte aligned, n % (16 / esz) == 0 */
+int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, float sx, long n, int dtype, hipStream_t stream) {
   if (!dx || !dy || !x || !gx || !(al16(dx) && al16(dy) && al16(x) && al16(gx))) return HDMOE_EINVAL;
-  DT_SWITCH(dtype, if (n % VT<T>::W == 0) L1D(mp_silu_bwd_add_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, (const T*)gx, n / VT<T>::W);
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0) L1D(mp_silu_bwd_add_vec_kernel<T>, n / VT<T>::W, (T*)dx, (const T*)dy, (const T*)x, (const T*)gx, sx, n / VT<T>::W);
                    else return HDMOE_EINVAL)
 }
 /* out = mp_cat(a, b) (weights wa, wb), out_h = mp_silu(out); Ca, Cb multiples of 16 / esz */

@@ -34,7 +34,7 @@ __global__ void pixelnorm_fwd_kernel(T* xn, T* h, const T* x, int C, long rows) 
 }
 // g = dxn + dh * mp_silu'(xn);  dx = g/d - x * (sum g*x) * rc / (d^2 * n)
 template <typename T>
-__global__ void pixelnorm_bwd_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows) {
+__global__ void pixelnorm_bwd_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows, float sx) {
   const float rc = rsqrtf((float)C);
   GRID_STRIDE(r, rows) {
     const T* p = x + r * C;
@@ -45,14 +45,14 @@ __global__ void pixelnorm_bwd_kernel(T* dx, const T* dxn, const T* dh, const T* 
     float dot = 0.f;
     for (int c = 0; c < C; ++c) {
       const float v = to_f(p[c]);
-      float g = dxn ? to_f(dxn[r * C + c]) : 0.f;
+      float g = dxn ? sx * to_f(dxn[r * C + c]) : 0.f;
       if (dh) g += to_f(dh[r * C + c]) * mp_silu_grad_f(v * inv);
       dot += g * v;
     }
     const float k2 = nrm > 0.f ? dot * rc * inv * inv / nrm : 0.f;
     for (int c = 0; c < C; ++c) {
       const float v = to_f(p[c]);
-      float g = dxn ? to_f(dxn[r * C + c]) : 0.f;
+      float g = dxn ? sx * to_f(dxn[r * C + c]) : 0.f;
       if (dh) g += to_f(dh[r * C + c]) * mp_silu_grad_f(v * inv);
       dx[r * C + c] = from_f<T>(g * inv - k2 * v);
     }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_vec_kernel(T* xn, T* h, con
   }
 }
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows) {
+__global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(T* dx, const T* dxn, const T* dh, const T* x, int C, long rows, float sx) {
   constexpr int W = VT<T>::W;
   const int sub = threadIdx.x % LPR;
   const bool act = sub * W < C;
@@ -263,7 +263,11 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(T* dx, const T* 
     for (int j = 0; j < W; ++j) { v[j] = 0.f; g[j] = 0.f; }
     if (act) {
       vload<T>(v, x + r * C + sub * W);
-      if (dxn) vload<T>(g, dxn + r * C + sub * W);
+      if (dxn) {
+        vload<T>(g, dxn + r * C + sub * W);
+#pragma unroll
+        for (int j = 0; j < W; ++j) g[j] *= sx;
+      }
 #pragma unroll
       for (int j = 0; j < W; ++j) ss += v[j] * v[j];
     }
@@ -624,14 +628,14 @@ int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int 
   DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_fwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)xn, (T*)h, (const T*)x, C, rows))
   return hdmoe_launch_status();
 }
-int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, int dtype, hipStream_t stream) {
+int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, float sx, int dtype, hipStream_t stream) {
   if (!dxn && !dh) return HDMOE_EINVAL;
   DT_SWITCH(dtype, if (row_vec_ok<T>(C, dx, dxn, dh, x)) {
     const int lpr = lpr_for<T>(C);
-    LPR_SWITCH(lpr, hipLaunchKernelGGL((pixelnorm_bwd_vec_kernel<T, L>), dim3(rows_grid(rows, lpr)), dim3(256), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows))
+    LPR_SWITCH(lpr, hipLaunchKernelGGL((pixelnorm_bwd_vec_kernel<T, L>), dim3(rows_grid(rows, lpr)), dim3(256), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows, sx))
     return hdmoe_launch_status();
   })
-  DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_bwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows))
+  DT_SWITCH(dtype, hipLaunchKernelGGL(pixelnorm_bwd_kernel<T>, dim3(grid_for(rows)), dim3(TPB), 0, stream, (T*)dx, (const T*)dxn, (const T*)dh, (const T*)x, C, rows, sx))
   return hdmoe_launch_status();
 }
 static int gn_check(int N, int C, int G) {

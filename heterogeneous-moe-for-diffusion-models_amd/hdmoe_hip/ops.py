@@ -354,7 +354,7 @@ class _MPConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, seg, meta, *tensors):
-        (G, gain_val, alpha, beta, ones, training, normalize, split) = meta
+        (G, gain_val, alpha, beta, ones, training, normalize, split, res_raw) = meta
         weights, gains = tensors[:G], list(tensors[G:]) or None
         x = _c(x)
         N, H, W, Cphys = x.shape
@@ -395,13 +395,13 @@ class _MPConvFn(torch.autograd.Function):
         _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys, split), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
                seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, dtc)
         ctx.save_for_backward(x, seg, *tensors)
-        ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None, split)
+        ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None, split, res_raw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, seg, *tensors = ctx.saved_tensors
-        G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, has_res, split = ctx.meta
+        G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, has_res, split, res_raw = ctx.meta
         weights, gains = tensors[:G], list(tensors[G:]) or None
         dy = _c(dy)
         N, H, W, Cphys = x.shape
@@ -422,8 +422,11 @@ class _MPConvFn(torch.autograd.Function):
             _timed("conv_fwd", _conv_info(dy, seg, N, H, W, I, O, Cphys, khs, kws, O, split), "hdmoe_conv_fwd", dy, wd, dx, None, alpha, 0.0,
                    seg, G, wdstride, N, Ho, Wo, H, W, O, O, Opad, I, Cphys, 1, 0, khs, kws, pt_d, pl_d, F32S if split else _dt(x))
         if has_res and nig[1]:
-            dres = torch.empty_like(dy)
-            call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
+            if res_raw or beta == 1.0:
+                dres = dy                                     # beta == 1, or the producer of `res` applies beta in its own backward pass
+            else:
+                dres = torch.empty_like(dy)
+                call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
         dws: List[Optional[Tensor]] = [None] * G
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
         if need_w and ctx.ent is not None:
@@ -467,7 +470,8 @@ def _split_ok(x4: Tensor, ws, ones: bool) -> bool:
 
 
 def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: Optional[Tensor] = None, alpha: float = 1.0,
-            beta: float = 0.0, ones: bool = False, training: bool = False, normalize: bool = True, split: bool = False) -> Tensor:
+            beta: float = 0.0, ones: bool = False, training: bool = False, normalize: bool = True, split: bool = False,
+            res_grad_raw: bool = False) -> Tensor:
     """Magnitude-preserving conv / linear (reference MP_Conv.forward, model_internals.py:253-275).
 
     ``x``: (N,H,W,C) -> (N,Ho,Wo,O);  (N,S,C) -> (N,S,O);  (M,C) -> (M,O).  ``weights``: a tensor, or a list of
@@ -499,7 +503,9 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
     if res is not None:
         res = res.reshape(x4.shape[0], x4.shape[1], x4.shape[2], -1)
     split = bool(split) and _split_ok(x4, ws, ones)
-    meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize), split)
+    # res_grad_raw: the gradient handed back for `res` is dy itself, NOT beta * dy -- only for a `res` whose producer was created with
+    # gx_scale = beta (ops.silu_branch / ops.pixel_norm_silu) and has no other consumer: saves a scaling pass per residual block
+    meta = (G, gain_val, float(alpha), float(beta), bool(ones), bool(training), bool(normalize), split, bool(res_grad_raw))
     y = _MPConvFn.apply(x4, res, seg, meta, *ws, *gts)
     return y.reshape(*shape[:-1], y.shape[-1])
 
@@ -924,26 +930,31 @@ class _SiluBranchFn(torch.autograd.Function):
     Backward: ONE pass, dx = gx + gh * mp_silu'(x) (instead of mp_silu_bwd + a gradient-sum launch)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, gx_scale):
         ctx.set_materialize_grads(False)
         x = _c(x)
         h = torch.empty_like(x)
         call("hdmoe_mp_silu_fwd", h, x, x.numel(), _dt(x))
         ctx.save_for_backward(x)
+        ctx.sx = float(gx_scale)
         return x.view(x.shape), h
 
     @staticmethod
     def backward(ctx, gx, gh):
         (x,) = ctx.saved_tensors
         if gh is None:
-            return gx
+            if gx is None or ctx.sx == 1.0:
+                return gx, None
+            dx = torch.empty_like(x)
+            call("hdmoe_axpby", dx, _c(gx), None, ctx.sx, 0.0, dx.numel(), _dt(dx))
+            return dx, None
         gh = _c(gh)
         dx = torch.empty_like(x)
         if gx is None:
             call("hdmoe_mp_silu_bwd", dx, gh, x, x.numel(), _dt(x))
         else:
-            call("hdmoe_mp_silu_bwd_add", dx, gh, x, _c(gx), x.numel(), _dt(x))
-        return dx
+            call("hdmoe_mp_silu_bwd_add", dx, gh, x, _c(gx), ctx.sx, x.numel(), _dt(x))
+        return dx, None
 
 
 class _CatSiluFn(torch.autograd.Function):
@@ -980,12 +991,34 @@ def _vec_ok(*ts) -> bool:
     return all(t.shape[-1] % (8 if t.dtype == torch.bfloat16 else 4) == 0 and t.dtype in (torch.bfloat16, torch.float32) for t in ts)
 
 
-def silu_branch(x: Tensor):
-    """(x, mp_silu(x)): the pair a decoder block needs (x continues on the skip / residual path)."""
+def silu_branch(x: Tensor, gx_scale: float = 1.0):
+    """(x, mp_silu(x)): the pair a decoder block needs (x continues on the skip / residual path).  ``gx_scale``: factor applied to
+    the gradient arriving for the returned x (see mp_conv(res_grad_raw=True))."""
     if _vec_ok(x) and x.numel() % 8 == 0:
-        return _SiluBranchFn.apply(x)
+        return _SiluBranchFn.apply(x, float(gx_scale))
     x, xh = fanout(x, 2)
+    if gx_scale != 1.0:
+        x = affine_grad(x, gx_scale)
     return x, mp_silu(xh)
+
+
+class _GradScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        dx = torch.empty_like(g)
+        call("hdmoe_axpby", dx, g, None, ctx.s, 0.0, g.numel(), _dt(g))
+        return dx, None
+
+
+def affine_grad(x: Tensor, s: float) -> Tensor:
+    """Identity in the forward, gradient times ``s`` in the backward (the unfused form of a deferred residual-gradient scale)."""
+    return _GradScaleFn.apply(x, float(s))
 
 
 def mp_cat_silu(a: Tensor, b: Tensor, t: float = 0.5):
@@ -1392,7 +1425,8 @@ def pixel_shuffle_tokens(tok: Tensor, H: int, W: int, C: int, p: int) -> Tensor:
 # =====================================================================================================
 class _PixelNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, with_silu):
+    def forward(ctx, x, with_silu, gx_scale=1.0):
+        ctx.sx = float(gx_scale)
         x = _c(x)
         C = x.shape[-1]
         xn = torch.empty_like(x)
@@ -1409,18 +1443,19 @@ class _PixelNormFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         C = x.shape[-1]
         dx = torch.empty_like(x)
-        call("hdmoe_pixelnorm_bwd", dx, _c(dxn), _c(dh), x, x.numel() // C, C, _dt(x))
-        return dx, None
+        call("hdmoe_pixelnorm_bwd", dx, _c(dxn), _c(dh), x, x.numel() // C, C, ctx.sx, _dt(x))
+        return dx, None, None
 
 
 def pixel_norm(x: Tensor) -> Tensor:
     """normalize(x, dim=[channel]) (model_internals.py:8-30)."""
-    return _PixelNormFn.apply(x, False)
+    return _PixelNormFn.apply(x, False, 1.0)
 
 
-def pixel_norm_silu(x: Tensor):
-    """Returns (normalize(x, channel), mp_silu(of that)) in one pass (model_components.py:238-240)."""
-    return _PixelNormFn.apply(x, True)
+def pixel_norm_silu(x: Tensor, gx_scale: float = 1.0):
+    """Returns (normalize(x, channel), mp_silu(of that)) in one pass (model_components.py:238-240).  ``gx_scale``: factor applied to
+    the gradient arriving for the FIRST output (see mp_conv(res_grad_raw=True))."""
+    return _PixelNormFn.apply(x, True, float(gx_scale))
 
 
 class _GroupNormFn(torch.autograd.Function):

@@ -126,20 +126,29 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
     x = ops.resample(x, b0.resample)
     t = b0.residual_balance
     n = ((1.0 - t) ** 2 + t ** 2) ** 0.5
+    # The residual x enters conv_res2's epilogue as beta * x.  Its gradient beta * dy would be a scaling pass per block: instead
+    # beta is applied where the gradient is consumed anyway (the backward of the op that produced x), or -- when a conv_skip sits
+    # in between -- folded into that conv's weights, and conv_res2 hands dy back as it is (res_grad_raw).
+    beta = (1.0 - t) / n
+    raw = False
     if b0.type == "enc":
         if b0.conv_skip is not None:
             x = conv("conv_skip", x)
-        x, h = ops.pixel_norm_silu(x)
+        x, h = ops.pixel_norm_silu(x, gx_scale=beta)
+        raw = True
     elif silu_x is not None:
         h = silu_x                                             # the caller fused mp_silu into the producer of x (ops.mp_cat_silu)
     else:
-        x, h = ops.silu_branch(x)                              # main branch + skip / residual: one fused backward pass
+        skip_next = b0.conv_skip is not None
+        x, h = ops.silu_branch(x, gx_scale=1.0 if skip_next else beta)     # main branch + skip / residual: one fused backward pass
+        raw = not skip_next
     y = conv("conv_res1", h, b0.conv_gain1)
     y = ops.film_silu(y, emb, b0.dropout, tr)                 # FiLM * emb -> mp_silu -> F.dropout, one pass
     if b0.type == "dec" and b0.conv_skip is not None:
-        x = conv("conv_skip", x)
+        x = conv("conv_skip", x, alpha=beta)                   # beta folded into the skip projection's weight image
+        return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=1.0)
     # conv_res2 with mp_sum(x, main, residual_balance) fused into its epilogue
-    return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=(1.0 - t) / n)
+    return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=beta, res_grad_raw=raw)
 
 
 class Unet_block(nn.Module):

@@ -98,7 +98,7 @@ int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS strea
 int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, HS stream);
 int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, HS stream);
 /* fused decoder-block entry (model_components.py:232-253): the block input feeds mp_silu AND the skip / residual path */
-int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, long n, int dtype, HS stream);   /* dx = gx + dy * mp_silu'(x) */
+int hdmoe_mp_silu_bwd_add(void* dx, const void* dy, const void* x, const void* gx, float sx, long n, int dtype, HS stream);   /* dx = sx * gx + dy * mp_silu'(x) */
 int hdmoe_cat2_silu_fwd(void* out, void* out_h, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows,
                         int dtype, HS stream);                                                                     /* out = mp_cat, out_h = mp_silu(out) */
 int hdmoe_cat2_silu_bwd(void* da, void* db, const void* gcat, const void* gh, const void* xcat, float wa, float wb, int Ca,
@@ -152,7 +152,7 @@ int hdmoe_seed_advance(unsigned long long* seed_dev, HS stream);
 
 /* ---- K6: norms  (model_internals.py:8-30; nn.GroupNorm / nn.LayerNorm in model_components.py) ------------ */
 int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, HS stream);               /* h = mp_silu(xn), optional */
-int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, int dtype, HS stream);
+int hdmoe_pixelnorm_bwd(void* dx, const void* dxn, const void* dh, const void* x, long rows, int C, float sx, int dtype, HS stream);   /* sx scales dxn */
 int hdmoe_groupnorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int N,
                         long S, int C, int G, int act, float eps, int dtype, HS stream);                         /* act: 0 none, 1 relu, 2 mp_silu */
 int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dy, const void* x,
