@@ -1,0 +1,73 @@
+// Input gradient AND weight gradient of a k x k bf16 expert layer in ONE launch ("horizontal" fusion): the first G6 workgroups run the
+// conv6 program on dy with the flipped weights (dgrad), the others the wgrad6 programs (3x3 class, then 5x5 class) on (x, dy).
+// The two are independent, both read dy, and on this model's layer sizes each alone is dominated by its fixed costs (launch, pipeline
+// prologue, tail of a persistent grid): back to back they cost ~30 + ~40 us per layer on the backward chain of the U-Net branch,
+// side by side in one grid about the longer of the two.  A fork onto a second stream inside the graph would also overlap them, but a
+// hipGraph with internal branches no longer runs concurrently with the other branch's graph (measured: the ViT backward graph then
+// waits for the whole U-Net backward graph).
+#include <stdlib.h>
+#include "common.h"
+#include "conv_args.h"
+#include "conv6_common.h"
+#include "hdmoe.h"
+#include "conv6_body.h"
+#include "wgrad6_body.h"
+
+namespace {
+
+template <int MT, int NT, int TWS, int OT>
+__global__ __launch_bounds__(512) void bwd6_kernel(C6Args c, W6Args a3, W6Args a5, int G6, int ibs, int obs) {
+  const int b = blockIdx.x;
+  if (b < G6) { conv6_body<MT, NT>(c, b, G6); return; }
+  int r = b - G6;
+  const int bx = r % ibs; r /= ibs;
+  const int by = r % obs;
+  const int z = r / obs;
+  if (z < a3.chunks) wgrad6_body<3, TWS, OT, false>(a3, bx, by, z);
+  else wgrad6_body<5, TWS, OT, false>(a5, bx, by, z - a3.chunks);
+}
+
+template <int MT, int NT, int TWS, int OT>
+void launch_bwd6(const C6Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd6_kernel<MT, NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
+  const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
+  hipLaunchKernelGGL((bwd6_kernel<MT, NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* dx = alpha * dgrad(dy, wd)  and  partial slabs of dW into ws (deferred reduction, as hdmoe_conv_wgrad6(..., defer = 1)) for one grouped
+ * k x k bf16 layer with 3x3 and 5x5 experts (stride 1, "same" padding pt = (k - 1) / 2).  wd: flipped dgrad weight image
+ * [g][tap][Cin][Cout] (hdmoe_wprep_fwd / the weight bank).  Returns 1 without launching when the layer is outside the domain. */
+int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups, long wd_stride,
+                    int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, const int* pt, const int* pl, float alpha,
+                    void* ws, long ws_bytes, int dtype, hipStream_t stream) {
+  static const bool off = getenv("HDMOE_BWD6") && atoi(getenv("HDMOE_BWD6")) == 0;
+  if (off || dtype != HDMOE_BF16 || !dx || !wd || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || Cout % 16) return 1;
+  W6DualPlan wp;
+  if (wgrad6_plan_dual(x, dy, G, seg, ngroups, N, H, W, Cin, Cout, kh, kw, pt, pl, ws, ws_bytes, dtype, wp)) return 1;
+  ConvArgs c;                                              // the dgrad as a forward conv over dy
+  c.x = dy; c.w = wd; c.y = dx; c.res = nullptr; c.seg = seg; c.wstride = wd_stride;
+  c.N = N; c.H = H; c.W = W; c.Ho = H; c.Wo = W; c.Cin = Cout; c.Cphys = Cout; c.Ipad = Cout; c.Cout = Cin; c.Cstore = Cin;
+  c.stride = 1; c.ones = 0; c.ngroups = ngroups; c.n0 = 0; c.alpha = alpha; c.beta = 0.f;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    c.kh[g] = kh[s]; c.kw[g] = kw[s]; c.pt[g] = kh[s] - 1 - pt[s]; c.pl[g] = kw[s] - 1 - pl[s];
+  }
+  C6Plan cp;
+  if (conv6_plan(c, dtype, cp)) return 1;
+#define BWD6_GO(M, Nt)                                                                           \
+  do {                                                                                           \
+    if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd6<M, Nt, 5, 2>(cp, wp, stream); else launch_bwd6<M, Nt, 5, 1>(cp, wp, stream); } \
+    else { if (wp.OT == 2) launch_bwd6<M, Nt, 4, 2>(cp, wp, stream); else launch_bwd6<M, Nt, 4, 1>(cp, wp, stream); }            \
+  } while (0)
+  if (cp.MT == 2) { if (cp.NT == 2) BWD6_GO(2, 2); else BWD6_GO(2, 1); }
+  else { if (cp.NT == 2) BWD6_GO(1, 2); else BWD6_GO(1, 1); }
+  return hdmoe_launch_status();
+}
+
+}  // extern "C"

@@ -34,3 +34,8 @@ constexpr int C6_NW = 8;              // waves per workgroup: two per SIMD.  (On
 
 
 }  // namespace
+
+struct ConvArgs;
+struct C6Plan { C6Args a; int MT, NT; unsigned G; size_t lds; };
+// Launch geometry of conv6 for one layer (conv6.hip).  0 = planned, 1 = outside conv6's domain.
+int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan);

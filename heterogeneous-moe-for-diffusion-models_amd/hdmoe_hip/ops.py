@@ -300,6 +300,7 @@ class _W6Arena:
 
 _w6_arenas = {}
 W6_DEFER = _os.environ.get("HDMOE_W6_DEFER", "1") != "0"
+BWD6 = _os.environ.get("HDMOE_BWD6", "1") != "0"          # dgrad + wgrad of a k x k expert layer in one launch (csrc/bwd6.hip)
 
 
 def w6_arena_reset(device) -> None:
@@ -411,7 +412,27 @@ class _MPConvFn(torch.autograd.Function):
         nig = ctx.needs_input_grad
         need_gain = gains is not None and any(nig[4 + G + g] for g in range(G))
         need_w = any(nig[4 + g] for g in range(G)) or need_gain
-        if nig[0]:
+        fused = False
+        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and PROFILE is None and x.dtype == torch.bfloat16 and not split
+                and not ones and Ho == H and Wo == W and Cphys == I and set(khs) == {3, 5} and khs == kws):
+            # input gradient + (deferred) weight gradient of a 3x3 / 5x5 expert layer in one launch (csrc/bwd6.hip)
+            from ._lib import lib, _int_array
+            import ctypes
+            kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
+                                                 ctypes.cast(_int_array(kws), ctypes.c_void_p), _dt(x))
+            ws = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
+            if ws is not None:
+                dx = torch.empty_like(x)
+                Opad = (O + 15) // 16 * 16
+                wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
+                if call("hdmoe_conv_bwd6", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, N, H, W, I, O, khs, kws, pts, pts, alpha,
+                        ws, ws.numel() * 4, _dt(x)) == 0:
+                    ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, _dt(x), 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
+                    ctx.bank.note_backward(ctx.ent)
+                    fused = True
+                else:
+                    dx = None
+        if nig[0] and not fused:
             Opad = (O + 15) // 16 * 16
             wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
             wd = ctx.wd
@@ -429,7 +450,9 @@ class _MPConvFn(torch.autograd.Function):
                 call("hdmoe_axpby", dres, dy, None, beta, 0.0, dy.numel(), _dt(dy))
         dws: List[Optional[Tensor]] = [None] * G
         dgs: List[Optional[Tensor]] = [None] * (len(tensors) - G)
-        if need_w and ctx.ent is not None:
+        if fused:
+            pass
+        elif need_w and ctx.ent is not None:
             # bank path: accumulate into the bank's slab; one multi-tensor launch at the end of backward finishes every gradient
             _wgrad(_conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys), x, dy, ctx.ent.G, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws, pts, split,
                    bank=ctx.bank)

@@ -76,6 +76,12 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
 /* defer != 0: the partial slabs stay in `ws` (2 x ws_kib KiB: one region per kernel-size class) and are summed into G later by ONE
  * batched launch per 16 (layer, class) items.  Per deferred call i: G + 8 i = its per-expert slabs, seg[i], ws[i], and
  * dims + 16 i = {ngroups, N, H, W, Cin, Cout, dtype, 0, kh[0..7]}. */
+/* Input gradient and (deferred) weight gradient of one grouped k x k bf16 layer with 3x3 and 5x5 experts in ONE launch (csrc/bwd6.hip):
+ * dx = alpha * dgrad(dy, wd) like hdmoe_conv_fwd on the flipped image, partial dW slabs into ws like hdmoe_conv_wgrad6(defer = 1).
+ * Returns 1 without launching when the layer is outside the domain. */
+int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups,
+                    long wd_stride, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, const int* pt,
+                    const int* pl, float alpha, void* ws, long ws_bytes, int dtype, HS stream);
 int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, HS stream);
 
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
