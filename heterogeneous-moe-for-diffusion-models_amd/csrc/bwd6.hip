@@ -12,6 +12,7 @@
 #include "hdmoe.h"
 #include "conv6_body.h"
 #include "wgrad6_body.h"
+#include "conv6s_body.h"
 
 namespace {
 
@@ -36,9 +37,52 @@ void launch_bwd6(const C6Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
   hipLaunchKernelGGL((bwd6_kernel<MT, NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
 }
 
+// The same for a router-trunk layer (fp32 tensors on the bf16 pipe: conv6_split program + wgrad6<SPLIT> program).
+template <int NT, int TWS, int OT>
+__global__ __launch_bounds__(512) void bwd6s_kernel(C6SArgs c, W6Args a3, int G6, int ibs, int obs) {
+  const int b = blockIdx.x;
+  if (b < G6) { conv6s_body<NT>(c, b, G6); return; }
+  int r = b - G6;
+  const int bx = r % ibs; r /= ibs;
+  wgrad6_body<3, TWS, OT, true>(a3, bx, r % obs, r / obs);
+}
+template <int NT, int TWS, int OT>
+void launch_bwd6s(const C6SPlan& cp, const W6DualPlan& wp, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd6s_kernel<NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
+  const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * wp.c[0].chunks);
+  hipLaunchKernelGGL((bwd6s_kernel<NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.sa, wp.c[0], (int)cp.G, wp.ibs, wp.obs);
+}
+
 }  // namespace
 
 extern "C" {
+
+/* hdmoe_conv_bwd6 for fp32 tensors computed as split bf16 (3x3 layers of the router trunks): wd = [hi | lo] bf16 dgrad image with
+ * `wd_plane` elements per plane. */
+int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups, long wd_stride,
+                     long wd_plane, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, const int* pt, const int* pl,
+                     float alpha, void* ws, long ws_bytes, hipStream_t stream) {
+  static const bool off = getenv("HDMOE_BWD6") && atoi(getenv("HDMOE_BWD6")) == 0;
+  if (off || !dx || !wd || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || Cout % 16) return 1;
+  W6DualPlan wp;
+  if (wgrad6_plan_split(x, dy, G, seg, ngroups, N, H, W, Cin, Cout, kh, kw, pt, pl, ws, ws_bytes, wp)) return 1;
+  ConvArgs c;
+  c.x = dy; c.w = wd; c.y = dx; c.res = nullptr; c.seg = seg; c.wstride = wd_stride;
+  c.N = N; c.H = H; c.W = W; c.Ho = H; c.Wo = W; c.Cin = Cout; c.Cphys = Cout; c.Ipad = Cout; c.Cout = Cin; c.Cstore = Cin;
+  c.stride = 1; c.ones = 0; c.ngroups = ngroups; c.n0 = 0; c.alpha = alpha; c.beta = 0.f;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { c.kh[g] = 3; c.kw[g] = 3; c.pt[g] = 1; c.pl[g] = 1; }
+  C6SPlan cp;
+  if (conv6s_plan(c, wd_plane, nullptr, cp)) return 1;
+#define BWD6S_GO(Nt)                                                                             \
+  do {                                                                                           \
+    if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd6s<Nt, 5, 2>(cp, wp, stream); else launch_bwd6s<Nt, 5, 1>(cp, wp, stream); } \
+    else { if (wp.OT == 2) launch_bwd6s<Nt, 4, 2>(cp, wp, stream); else launch_bwd6s<Nt, 4, 1>(cp, wp, stream); }            \
+  } while (0)
+  if (cp.NT == 2) BWD6S_GO(2); else BWD6S_GO(1);
+  return hdmoe_launch_status();
+}
 
 /* dx = alpha * dgrad(dy, wd)  and  partial slabs of dW into ws (deferred reduction, as hdmoe_conv_wgrad6(..., defer = 1)) for one grouped
  * k x k bf16 layer with 3x3 and 5x5 experts (stride 1, "same" padding pt = (k - 1) / 2).  wd: flipped dgrad weight image

@@ -20,323 +20,19 @@
 #include "conv_args.h"
 #include "conv6_common.h"
 #include "hdmoe.h"
+#include "conv6s_body.h"
 
 namespace {
 
-struct C6SArgs {
-  C6Args c;
-  int wplane;                         // bytes between the hi and the lo weight image
-  const float* in_scale; const float* in_shift; int in_relu;   // fused input transform (or null)
-  float* stats;                       // [N][2] fp32 accumulators (sum, sum of squares of the outputs), or null
-};
-
 template <int NT>
 __global__ __launch_bounds__(64 * C6_NW) void conv6_split_kernel(C6SArgs sa) {
-#if __HIP_DEVICE_COMPILE__
-  const C6Args& a = sa.c;
-  constexpr int MT = 2, NB = 32 * NT, PPT = NB / 16, NW = C6_NW, MB = 8 * MT / NW;
-  constexpr int NHP = 11;                      // 8-pixel half pieces per wave: 2 tiles x 22 pieces x 2 / 8 waves (3x3 halo of a 256-pixel tile)
-  constexpr int NWP = 40 / NW;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int csl = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;     // weight DMA: swizzled 16-B slot of this lane
-  const int prow = lane >> 2;
-  const int G = gridDim.x;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
-
-  // ---- unit list (see conv6.hip): slot oi of the descending-kernel-size group list lives in lane oi
-  const int oi_l = lane & 7;
-  int v_g = 0, v_ks = 0, v_pt = 0, v_pl = 0;
-#pragma unroll
-  for (int oi = 0; oi < HDMOE_MAX_GROUPS; ++oi) v_g = oi_l == oi ? a.order[oi] : v_g;
-#pragma unroll
-  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
-    const bool me = v_g == g;
-    v_ks = me ? a.ks[g] : v_ks; v_pt = me ? a.pt[g] : v_pt; v_pl = me ? a.pl[g] : v_pl;
-  }
-  const bool slot_ok = lane < a.ngroups;
-  const int v_row0 = (a.seg && slot_ok) ? a.seg[v_g] : 0;
-  const int v_rows = !slot_ok ? 0 : (a.seg ? a.seg[v_g + 1] - v_row0 : a.N);
-  const int v_tiles = v_rows * a.tpi;
-  const int v_units = (v_tiles + MT - 1) / MT;
-  int v_ustart = v_units;
-#pragma unroll
-  for (int d = 1; d < 8; d <<= 1) {
-    const int o = __shfl_up(v_ustart, d, 8);
-    if (oi_l >= d) v_ustart += o;
-  }
-  const int total = __builtin_amdgcn_readlane(v_ustart, 7) * a.nblk;
-  v_ustart -= v_units;
-  auto udiv = [](int x, unsigned magic, int d) {
-    int q = (int)(((unsigned long long)(unsigned)x * magic) >> 32);
-    if (q * d > x) --q;
-    if ((q + 1) * d <= x) ++q;
-    return q;
-  };
-  auto decode = [&](int j, C6Unit<MT>& u) {
-    const int uu0 = udiv(j, a.m_nblk, a.nblk);
-    u.nbk = j - uu0 * a.nblk;
-    const unsigned long long hit = __ballot(lane < 8 && uu0 >= v_ustart && uu0 < v_ustart + v_units);
-    const int slot = (int)__builtin_ctzll(hit | (1ull << 7));
-    const int uu = uu0 - __builtin_amdgcn_readlane(v_ustart, slot);
-    const int row0 = __builtin_amdgcn_readlane(v_row0, slot), tiles = __builtin_amdgcn_readlane(v_tiles, slot);
-    u.g = __builtin_amdgcn_readlane(v_g, slot); u.ks = __builtin_amdgcn_readlane(v_ks, slot);
-    u.pt = __builtin_amdgcn_readlane(v_pt, slot); u.pl = __builtin_amdgcn_readlane(v_pl, slot);
-    u.ntaps = u.ks * u.ks; u.ntg = udiv(u.ntaps + a.T - 1, a.m_T, a.T);
-    u.HWp = a.TW + u.ks - 1; u.HHp = a.TH + u.ks - 1; u.ppt = (u.HWp * u.HHp + 15) >> 4;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int tt = uu * MT + m;
-      u.valid[m] = tt < tiles;
-      const int ttc = u.valid[m] ? tt : tiles - 1;
-      const int img = udiv(ttc, a.m_tpi, a.tpi), ti = ttc - img * a.tpi;
-      const int tyi = udiv(ti, a.m_tx, a.tiles_x);
-      u.n[m] = row0 + img; u.ty0[m] = tyi * a.TH; u.tx0[m] = (ti - tyi * a.tiles_x) * a.TW;
-    }
-  };
-  auto wbase_of = [&](const C6Unit<MT>& u) { return (int)(((long)u.g * a.wstride + (long)u.nbk * NB * a.Cin) * 2); };
-
-  // ---- halo staging through registers.  Half piece hp = wave + 8k = 8 pixels x 32 fp32 channels (1 KB): lane = (pixel hp*8 + lane/8,
-  // channels 4*(lane%8) ..+3).  ho[k]: byte offset of the lane's 16 B inside x at chunk 0 (~0 = padding / beyond the unit: reads 0).
-  const int cq = lane & 7;
-  auto plan = [&](const C6Unit<MT>& u, unsigned (&ho)[NHP]) {
-    const int magic = (1 << 20) / u.HWp + 1;
-    const int npx = u.HWp * u.HHp;
-    const int cin4 = a.Cin * 4;
-#pragma unroll
-    for (int k = 0; k < NHP; ++k) {
-      const int hp = wave + NW * k;
-      const int pxu = 8 * hp + (lane >> 3);                   // pixel inside the unit's two-tile halo image
-      const bool t1 = pxu >= u.ppt * 16;
-      const int px = pxu - (t1 ? u.ppt * 16 : 0);
-      int hy = (int)(((unsigned)px * (unsigned)magic) >> 20);
-      if (hy * u.HWp > px) --hy;
-      const int hx = px - hy * u.HWp;
-      const int n = t1 ? u.n[1] : u.n[0];
-      const int iy = (t1 ? u.ty0[1] : u.ty0[0]) - u.pt + hy, ix = (t1 ? u.tx0[1] : u.tx0[0]) - u.pl + hx;
-      const bool ok = pxu < 2 * u.ppt * 16 && px < npx && (t1 ? u.valid[1] : u.valid[0]) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      ho[k] = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * cin4 + cq * 16) : 0xFFFFFFFFu;
-    }
-  };
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  auto nhp_of = [&](int ppt) { return (2 * ppt * 2 + NW - 1) / NW; };     // half pieces per wave (2 tiles x ppt pieces x 2)
-  auto halo_load = [&](const unsigned (&ho)[NHP], int c, f4 (&rh)[NHP], int nhp) {
-#pragma unroll
-    for (int k = 0; k < NHP; ++k)
-      if (k < nhp) rh[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ho[k], c * 128, 0));
-  };
-  // registers -> (input transform) -> hi / lo bf16 -> LDS images (XHI at 0, XLO at hb_bytes), conv6's swizzled [pixel][64 B] layout
-  auto halo_store = [&](const C6Unit<MT>& u, const unsigned (&ho)[NHP], int c, const f4 (&rh)[NHP]) {
-    const int nhp = nhp_of(u.ppt), npxu = 32 * u.ppt;
-#pragma unroll
-    for (int k = 0; k < NHP; ++k) {
-      if (k >= nhp) continue;
-      const int hp = wave + NW * k;
-      const int pxu = 8 * hp + (lane >> 3);
-      if (pxu >= npxu) continue;                              // (the last half piece may reach past the two-tile image)
-      f4 v = rh[k];
-      if (sa.in_scale && ho[k] != 0xFFFFFFFFu) {              // padding stays exactly zero (the reference pads AFTER the norm + ReLU)
-        const int ch = c * 32 + cq * 4;
-        const int n = 8 * hp >= u.ppt * 16 ? u.n[1] : u.n[0];  // (a half piece never straddles the two tiles: wave-uniform)
-        const f4 sc = *reinterpret_cast<const f4*>(sa.in_scale + (long)n * a.Cin + ch);
-        const f4 sh = *reinterpret_cast<const f4*>(sa.in_shift + (long)n * a.Cin + ch);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * sc[e] + sh[e]; if (sa.in_relu) v[e] = fmaxf(v[e], 0.f); }
-      }
-      bf16x4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
-      const int off = pxu * 64 + ((((cq >> 1) ^ ((pxu >> 2) & 3))) << 4) + ((cq & 1) << 3);
-      *reinterpret_cast<bf16x4*>(lds + off) = hi;
-      *reinterpret_cast<bf16x4*>(lds + a.hb_bytes + off) = lo;
-    }
-  };
-  // ---- weights (as conv6.hip; plane = 0 hi / 1 lo)
-  const unsigned wlo = (unsigned)((((wave / PPT) * a.Cout + (wave % PPT) * 16 + prow) * a.Cin) * 2 + csl);
-  const int wkstep = (NW / PPT) * a.Cout * a.Cin * 2;
-  auto issue_wpiece = [&](int sb, int k, int wbo) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wlo, sb + k * wkstep, 0, 0);
-  };
-  auto wpieces = [&](int ntl) { return max(0, (ntl - wave / PPT + (NW / PPT) - 1) / (NW / PPT)); };
-  auto stage_base = [&](int wbase, int plane, int c, int t0) { return wbase + plane * sa.wplane + (t0 * a.Cout * a.Cin + c * 32) * 2; };
-
-  int j = blockIdx.x;
-  if (j >= total) return;
-  C6Unit<MT> cur, nu;
-  decode(j, cur);
-  nu = cur;
-  unsigned hoc[NHP];                           // halo offsets of the unit whose chunks are being LOADED (cur, or nu from cur's last stage on)
-  f4 rh[NHP];
-  int wbase_cur = wbase_of(cur), wbase_nxt = 0;
-  int jn = j + G;
-  bool has_next = jn < total;
-  const int WB0 = 2 * a.hb_bytes;
-  const int nchunks = a.Cin >> 5;
-  const int wl = r * 64 + ((h << 4) ^ (((r >> 2) & 3) << 4));
-  const int mb0 = MB * wave;
-  const int tile_w = mb0 >> 3;
-  // prologue: first weight stage (DMA), first halo chunk (registers -> LDS)
-  {
-    const int sb = stage_base(wbase_cur, 0, 0, 0), np = wpieces(min(a.T, cur.ntaps));
-    for (int k = 0; k < np; ++k) issue_wpiece(sb, k, WB0);
-    plan(cur, hoc);
-    halo_load(hoc, 0, rh, nhp_of(cur.ppt));
-    halo_store(cur, hoc, 0, rh);
-  }
-  int sp = 0;
-
-  while (true) {
-    int P0[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int q = ((mb0 + m) & 7) * 32 + r;
-      P0[m] = tile_w * cur.ppt * 16 + (q >> a.tws) * cur.HWp + (q & (a.TW - 1));
-    }
-    f32x16 acc[MB][NT];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int b = 0; b < NT; ++b) acc[m][b] = (f32x16)(0.f);
-
-    for (int c = 0; c < nchunks; ++c) {
-      const bool last_chunk = c == nchunks - 1;
-      const bool more = !last_chunk || has_next;                    // another halo chunk follows (this unit's or the next unit's)
-      for (int prod = 0; prod < 3; ++prod) {                        // x_hi * w_hi, x_hi * w_lo, x_lo * w_hi
-        const int xoff = prod == 2 ? a.hb_bytes : 0;
-        int ky = 0, kx = 0;
-        for (int tg = 0; tg < cur.ntg; ++tg) {
-          const int t0 = tg * a.T;
-          const int ntl = min(a.T, cur.ntaps - t0);
-          const bool last_stage = prod == 2 && tg + 1 == cur.ntg;
-          __syncthreads();
-          // ---- next stage's weights
-          const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
-          int nsb = 0, nwp = 0;
-          if (tg + 1 < cur.ntg) { nsb = stage_base(wbase_cur, prod == 1, c, t0 + a.T); nwp = wpieces(min(a.T, cur.ntaps - t0 - a.T)); }
-          else if (prod < 2) { nsb = stage_base(wbase_cur, prod == 0, c, 0); nwp = wpieces(min(a.T, cur.ntaps)); }
-          else if (!last_chunk) { nsb = stage_base(wbase_cur, 0, c + 1, 0); nwp = wpieces(min(a.T, cur.ntaps)); }
-          else if (has_next) {
-            decode(jn, nu);
-            wbase_nxt = wbase_of(nu);
-            nsb = stage_base(wbase_nxt, 0, 0, 0); nwp = wpieces(min(a.T, nu.ntaps));
-          }
-          // ---- the next halo chunk's fp32 registers: loaded beside the chunk's last stage
-          if (last_stage && more) {
-            if (last_chunk) { plan(nu, hoc); halo_load(hoc, 0, rh, nhp_of(nu.ppt)); }   // (cur's own offsets are no longer needed)
-            else halo_load(hoc, c + 1, rh, nhp_of(cur.ppt));
-          }
-          auto side = [&](int k) { if (k < NWP && k < nwp) issue_wpiece(nsb, k, wbn); };
-          // ---- MFMA over the stage's taps (structure of conv6.hip)
-          const int hbpx = xoff >> 6;
-          const unsigned char* wb = lds + WB0 + sp * a.wb_bytes;
-          // software pipeline at k-step granularity (two per tap; a tap-deep pipeline as in conv6.hip needs 32 more registers than
-          // this kernel has beside the fp32 halo registers): set A always holds a tap's first 16 channels, set B its second
-          bf16x8 fxA[MB], fwA[NT], fxB[MB], fwB[NT];
-          int ad[MB];
-          auto tap_addr = [&]() {
-            const int toff = ky * cur.HWp + kx + hbpx;
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-              const int px = P0[m] + toff;
-              ad[m] = (px << 6) + (((px << 2) & 0x30) ^ (h << 4));
-            }
-            if (++kx == cur.ks) { kx = 0; ++ky; }
-          };
-          auto load_k = [&](bf16x8 (&fx)[MB], bf16x8 (&fw)[NT], int tl, int s2) {
-            const unsigned char* wt = wb + tl * NB * 64;
-#pragma unroll
-            for (int m = 0; m < MB; ++m) fx[m] = *reinterpret_cast<const bf16x8*>(lds + (ad[m] ^ (s2 << 5)));
-#pragma unroll
-            for (int b = 0; b < NT; ++b) fw[b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ (s2 << 5)));
-          };
-          auto mm = [&](const bf16x8 (&fx)[MB], const bf16x8 (&fw)[NT], bool first) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-              for (int b = 0; b < NT; ++b)
-                if ((m + b == 0) == first) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], fx[m], acc[m][b], 0, 0, 0);
-          };
-          tap_addr();
-          load_k(fxA, fwA, 0, 0);
-#pragma unroll
-          for (int tl = 0; tl < C6_MAXT; ++tl) {
-            if (tl < ntl) {
-              mm(fxA, fwA, true);
-              __builtin_amdgcn_sched_barrier(0);
-              load_k(fxB, fwB, tl, 1);
-              side(tl);
-              __builtin_amdgcn_sched_barrier(0);
-              mm(fxA, fwA, false);
-              mm(fxB, fwB, true);
-              __builtin_amdgcn_sched_barrier(0);
-              tap_addr();                                           // (runs one tap past the stage's last: read inside the buffer, never used)
-              load_k(fxA, fwA, min(tl + 1, ntl - 1), 0);
-              __builtin_amdgcn_sched_barrier(0);
-              mm(fxB, fwB, false);
-            } else {
-              side(tl);
-            }
-          }
-          if (kx == 0) { kx = cur.ks - 1; --ky; } else --kx;
-          sp ^= 1;
-        }
-      }
-      if (more) {
-        __syncthreads();                                            // every wave is done reading this chunk's hi / lo images
-        if (last_chunk) halo_store(nu, hoc, 0, rh);
-        else halo_store(cur, hoc, c + 1, rh);
-      }
-    }
-    // ---- epilogue: fp32, one 16-byte store per accumulator quad (4 consecutive channels of the lane's pixel)
-    {
-      float* Y = (float*)a.y;
-      const float* R = (const float*)a.res;
-      const int n = tile_w ? cur.n[1] : cur.n[0];
-      const int ty0 = tile_w ? cur.ty0[1] : cur.ty0[0], tx0 = tile_w ? cur.tx0[1] : cur.tx0[0];
-      const bool tv = tile_w ? cur.valid[1] : cur.valid[0];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const int q = ((mb0 + m) & 7) * 32 + r;
-        const int yy = ty0 + (q >> a.tws), xx = tx0 + (q & (a.TW - 1));
-        const bool ok = tv && yy < a.H && xx < a.W;
-        const long pix = (((long)n * a.H + yy) * a.W + xx) * a.Cout + cur.nbk * NB + 4 * h;
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            f4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = a.alpha * acc[m][b][4 * i + e];
-            if (ok) {
-              if (R) { const f4 rv = *reinterpret_cast<const f4*>(R + pix + 32 * b + 8 * i); v += a.beta * rv; }
-              *reinterpret_cast<f4*>(Y + pix + 32 * b + 8 * i) = v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-            }
-          }
-      }
-      if (sa.stats) {                                               // both tiles of a wave's blocks belong to one sample
-        s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0 && tv) { atomicAdd(sa.stats + 2 * (long)n, s1); atomicAdd(sa.stats + 2 * (long)n + 1, s2); }
-      }
-    }
-    if (!has_next) break;
-    cur = nu;
-    wbase_cur = wbase_nxt;
-    jn += G;
-    has_next = jn < total;
-  }
-#endif
+  conv6s_body<NT>(sa, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
 
 // x, y (and res) fp32; w = bf16 [hi | lo][g][tap][Cout][Cin] with `wplane_elems` elements between the two planes
-int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, hipStream_t stream) {
+int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SPlan& plan) {
   static const bool off = getenv("HDMOE_CONV6") && atoi(getenv("HDMOE_CONV6")) == 0;
   if (off) return 1;
   if (c.stride != 1 || c.ones || c.Cphys != c.Cin || c.Ipad != c.Cin || c.Cin % 32 || c.Cout % 32 || c.Cstore != c.Cout) return 1;
@@ -346,7 +42,7 @@ int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse*
   const long xbytes = (long)c.N * c.H * c.W * c.Cin * 4;
   const long wbytes = (wplane_elems + (long)(c.ngroups - 1) * c.wstride + 9l * c.Cout * c.Cin) * 2;
   if (xbytes >= (1l << 31) || wbytes >= (1l << 31) || (long)c.N * c.H * c.W * c.Cout >= (1l << 31)) return 1;
-  C6SArgs sa;
+  C6SArgs& sa = plan.sa;
   C6Args& a = sa.c;
   a.x = c.x; a.w = c.w; a.y = c.y; a.res = c.res; a.seg = c.seg; a.wstride = c.wstride;
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.ngroups = c.ngroups; a.alpha = c.alpha; a.beta = c.beta;
@@ -375,14 +71,21 @@ int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse*
   const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes;
   const long tiles = (long)c.N * a.tpi;
   long ub = ((tiles + 1) / 2 + c.ngroups) * a.nblk;
-  const unsigned G = (unsigned)(ub < 256 ? ub : 256);
+  plan.G = (unsigned)(ub < 256 ? ub : 256);
+  plan.NT = NT; plan.lds = lds;
+  return 0;
+}
+
+int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, hipStream_t stream) {
+  C6SPlan plan;
+  if (conv6s_plan(c, wplane_elems, fuse, plan)) return 1;
   static bool attr_set = false;
   if (!attr_set) {
     attr_set = true;
-    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CAP);
-    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CAP);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (NT == 2) hipLaunchKernelGGL(conv6_split_kernel<2>, dim3(G), dim3(64 * C6_NW), lds, stream, sa);
-  else hipLaunchKernelGGL(conv6_split_kernel<1>, dim3(G), dim3(64 * C6_NW), lds, stream, sa);
+  if (plan.NT == 2) hipLaunchKernelGGL(conv6_split_kernel<2>, dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+  else hipLaunchKernelGGL(conv6_split_kernel<1>, dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
   return hdmoe_launch_status();
 }

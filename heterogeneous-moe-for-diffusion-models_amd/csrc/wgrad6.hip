@@ -205,6 +205,37 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
   return 0;
 }
 
+// Launch geometry of the deferred split-bf16 (fp32 tensors, 3x3 only) weight gradient of one layer.  0 = planned, 1 = not applicable.
+int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin, int Cout,
+                      const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, W6DualPlan& p) {
+  static const bool off = getenv("HDMOE_WGRAD6") && atoi(getenv("HDMOE_WGRAD6")) == 0;
+  if (off) return 1;
+  const long need1 = 1024l * hdmoe_conv_wgrad6_ws_kib(ngroups, N, H, W, Cin, Cout, kh, kw, HDMOE_F32S);
+  if (need1 == 0 || !ws || ws_bytes < 2 * need1 || !x || !dy || !G || N == 0) return 1;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) return 1;
+  for (int g = 0; g < ngroups; ++g)
+    if (((uintptr_t)G[g] & 15) || kh[g] != 3 || kw[g] != 3 || pt[g] != 1 || pl[g] != 1) return 1;
+  const long xbytes = (long)N * H * W * Cin * 4, dybytes = (long)N * H * W * Cout * 4;
+  if (xbytes >= (1l << 31) || dybytes >= (1l << 31)) return 1;
+  const int TWS = W >= 32 ? 5 : 4, TW = 1 << TWS, TH = 256 / TW;
+  const int OT = Cout % 64 == 0 ? 2 : 1;
+  p.ibs = Cin / 32; p.obs = Cout / (32 * OT); p.TWS = TWS; p.OT = OT;
+  W6Args& a = p.c[0];
+  a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
+  a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
+  a.ngr = 0;
+  for (int g = 0; g < ngroups; ++g) a.groups[a.ngr++] = g;
+  a.pt = 1; a.pl = 1; a.ws_item = 9l * Cout * Cin;
+  int upw, slots;
+  w6_partition((long)N * a.tpi, a.ngr, ngroups, p.ibs, p.obs, upw, slots);
+  a.upw = upw; a.chunks = slots;
+  p.c[1] = a; p.c[1].chunks = 0;
+  const int HP16 = ((TW + 2) * (TH + 2) + 15) / 16;
+  p.lds = 2 * (size_t)(HP16 * 1024 + 16 * OT * 1024);
+  return 0;
+}
+
 extern "C" {
 
 // Same contract as hdmoe_conv_wgrad (G[g] += dW of group g, [tap][Cout][Cin] fp32) with a caller-provided workspace.

@@ -18,6 +18,10 @@ struct W6DualPlan { W6Args c[2]; int ibs, obs, TWS, OT; size_t lds; };
 int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin, int Cout,
                      const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, int dtype, W6DualPlan& p);
 
+// The same for the split-bf16 (fp32 tensors, 3x3) weight gradient: one class in c[0].
+int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin, int Cout,
+                      const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, W6DualPlan& p);
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lptr_t;

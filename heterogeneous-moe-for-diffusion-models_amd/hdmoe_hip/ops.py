@@ -432,6 +432,25 @@ class _MPConvFn(torch.autograd.Function):
                     fused = True
                 else:
                     dx = None
+        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and PROFILE is None and split and not ones and Ho == H and Wo == W
+                and Cphys == I and set(khs) == {3} and khs == kws):
+            # the same for a router-trunk layer (fp32 tensors, split-bf16 arithmetic)
+            from ._lib import lib, _int_array
+            import ctypes
+            kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
+                                                 ctypes.cast(_int_array(kws), ctypes.c_void_p), F32S)
+            ws = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
+            if ws is not None:
+                dx = torch.empty_like(x)
+                Opad = (O + 15) // 16 * 16
+                wdstride = 9 * I * Opad
+                if call("hdmoe_conv_bwd6s", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, G * wdstride, N, H, W, I, O, khs, kws, pts, pts,
+                        alpha, ws, ws.numel() * 4) == 0:
+                    ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, F32S, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
+                    ctx.bank.note_backward(ctx.ent)
+                    fused = True
+                else:
+                    dx = None
         if nig[0] and not fused:
             Opad = (O + 15) // 16 * 16
             wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad

@@ -82,6 +82,9 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
 int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups,
                     long wd_stride, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, const int* pt,
                     const int* pl, float alpha, void* ws, long ws_bytes, int dtype, HS stream);
+int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups,
+                     long wd_stride, long wd_plane, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw,
+                     const int* pt, const int* pl, float alpha, void* ws, long ws_bytes, HS stream);   /* fp32 tensors, split bf16 (3x3) */
 int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, HS stream);
 
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
