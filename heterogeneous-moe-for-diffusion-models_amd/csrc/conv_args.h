@@ -44,3 +44,4 @@ int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 // k x k fp32 weight gradient for tiny input channel counts (taps * Cin <= 64: the stem), one expert (lwgrad.hip).  Same return convention.
 int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
                    hipStream_t stream);
+

@@ -50,7 +50,11 @@ DEVI void lwg_flush(f32x16 (&acc)[OT][IT], float* red, float* G, int o0, int i0,
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) red[((wave * OT * IT + t * IT + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
   __syncthreads();
-  for (int e = tid; e < OT * IT * 1024; e += 256) {
+  // every workgroup of the launch adds into the same [32*OT][32*IT] tile: start each one at a different element so that they do
+  // not all queue on the same addresses at the same time
+  const int rot = (int)((blockIdx.z * 131u + blockIdx.x * 17u) % (unsigned)(OT * IT * 4)) * 256;
+  for (int e0 = tid; e0 < OT * IT * 1024; e0 += 256) {
+    const int e = (e0 + rot) % (OT * IT * 1024);
     const int l = e & 63, reg = (e >> 6) & 15, tu = e >> 10;
     float v = 0.f;
 #pragma unroll
@@ -206,29 +210,51 @@ __global__ __launch_bounds__(256) void swg_f32_kernel(SwgArgs a) {
   f32x16 acc[NBLK];
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc[b] = (f32x16)(0.f);
-  for (long pb = p0 + 2 * wave; pb < p1; pb += 8) {
-    const long p = pb + h;
-    const bool ok = p < p1;
-    const long pc = ok ? p : p0;
-    const int xw = (int)(pc % a.W);
-    const long t = pc / a.W;
-    const int yh = (int)(t % a.H);
-    const long img = t / a.H;
-    const float dv = ok ? a.dy[pc * a.Cout + o0 + r] : 0.f;
+  // 8 k-steps (16 pixels of this wave) per trip: all their loads are issued before the first MFMA (one step at a time the loop ran at
+  // one memory latency per step)
+  for (long base = p0; base < p1; base += 64) {
+    float dv[8], xv[8][NBLK];
+    bool okm[8], inm[8][NBLK];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-      const int yy = yh + ky[b], xx = xw + kx[b];
-      const bool in = ok && colok[b] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-      const float xv = in ? a.x[((img * a.H + yy) * a.W + xx) * a.Cin + ci[b]] : 0.f;
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, xv, acc[b], 0, 0, 0);
+    for (int st = 0; st < 8; ++st) {
+      const long p = base + 8 * st + 2 * wave + h;
+      const bool ok = p < p1;
+      const unsigned pc = (unsigned)(ok ? p : p0);               // 32-bit index arithmetic (64-bit div / mod cost ~500 instructions per step)
+      const unsigned t = pc / (unsigned)a.W;
+      const int xw = (int)(pc - t * (unsigned)a.W);
+      const unsigned img = t / (unsigned)a.H;
+      const int yh = (int)(t - img * (unsigned)a.H);
+      // unconditional loads from clamped (always valid) addresses, masks applied after ALL loads of the trip are in flight: a
+      // `cond ? load : 0` form made the compiler wait for every load before issuing the next (24 serial memory latencies per trip)
+      dv[st] = a.dy[(long)pc * a.Cout + o0 + r];
+      okm[st] = ok;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int yy = yh + ky[b], xx = xw + kx[b];
+        const bool in = ok && colok[b] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        inm[st][b] = in;
+        xv[st][b] = a.x[in ? (((long)img * a.H + yy) * a.W + xx) * a.Cin + ci[b] : 0];
+      }
     }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      dv[st] = okm[st] ? dv[st] : 0.f;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) xv[st][b] = inm[st][b] ? xv[st][b] : 0.f;
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[st], xv[st][b], acc[b], 0, 0, 0);
   }
 #pragma unroll
   for (int b = 0; b < NBLK; ++b)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) red[((wave * NBLK + b) * 16 + reg) * 64 + lane] = acc[b][reg];
   __syncthreads();
-  for (int e = tid; e < NBLK * 1024; e += 256) {
+  const int rot = (int)((blockIdx.x * 37u) % (unsigned)(NBLK * 4)) * 256;      // stagger the workgroups' atomic flushes (see lwg_flush)
+  for (int e0 = tid; e0 < NBLK * 1024; e0 += 256) {
+    const int e = (e0 + rot) % (NBLK * 1024);
     const int l = e & 63, reg = (e >> 6) & 15, b = e >> 10;
     float v = 0.f;
 #pragma unroll
@@ -247,12 +273,12 @@ __global__ __launch_bounds__(256) void swg_f32_kernel(SwgArgs a) {
 int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
                    hipStream_t stream) {
   static const bool off = getenv("HDMOE_SWG") && atoi(getenv("HDMOE_SWG")) == 0;
-  if (off || dtype != HDMOE_F32 || Cout % 32 || k * k * Cin > 64 || !x || !dy || !G) return 1;
+  if (off || dtype != HDMOE_F32 || Cout % 32 || k * k * Cin > 64 || !x || !dy || !G || (long)N * H * W >= (1l << 31)) return 1;
   SwgArgs a;
   a.x = (const float*)x; a.dy = (const float*)dy; a.G = G; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.pt = pt; a.pl = pl;
   const long total = (long)N * H * W;
-  long blocks = 512 / (Cout / 32); if (blocks < 1) blocks = 1;
-  long ppb = (total + blocks - 1) / blocks; ppb = (ppb + 7) / 8 * 8; if (ppb < 64) ppb = 64;
+  long blocks = 256 / (Cout / 32); if (blocks < 1) blocks = 1;       // one workgroup per CU: more only adds atomic flushes of the same 1152 words
+  long ppb = (total + blocks - 1) / blocks; ppb = (ppb + 63) / 64 * 64;
   a.ppb = ppb;
   const dim3 grid((unsigned)((total + ppb - 1) / ppb), Cout / 32);
   const int NBLK = (k * k * Cin + 31) / 32;

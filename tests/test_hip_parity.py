@@ -493,7 +493,7 @@ def test_full_model_real_widths(golden_wide, dtype, rel_out, rel_grad):
 # ----------------------------------------------------------------------------------------------- ops vs oracle at larger shapes
 @pytest.mark.parametrize("dtype,rel", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("cin,cout,k,hw", [(32, 32, 3, 32), (64, 32, 5, 16), (96, 64, 3, 16), (32, 4, 3, 32), (128, 128, 1, 8),
-                                           (33, 32, 3, 16), (4, 32, 3, 32), (3, 64, 3, 16), (2, 32, 5, 8)])
+                                           (33, 32, 3, 16), (4, 32, 3, 32), (3, 64, 3, 16), (2, 32, 5, 8), (32, 2, 1, 16), (64, 4, 3, 16)])
 def test_mp_conv_vs_oracle(dtype, rel, cin, cout, k, hw):
     from hdmoe_hip import ops
     from oracle import hdmoe_oracle as O
