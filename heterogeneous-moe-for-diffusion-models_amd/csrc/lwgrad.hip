@@ -83,14 +83,19 @@ __global__ __launch_bounds__(256) void lwg_bf16_kernel(LwgArgs a) {
     for (int k = 0; k < 4 * OT; ++k) {
       const int e = lane + 64 * k, q = e / (4 * OT), pc = e % (4 * OT);
       const long p = pb + q;
-      sdy[k] = p < p1 ? *reinterpret_cast<const uint4*>(DY + p * a.O + o0 + pc * 8) : make_uint4(0, 0, 0, 0);
+      sdy[k] = *reinterpret_cast<const uint4*>(DY + (p < p1 ? p : p0) * a.O + o0 + pc * 8);
     }
 #pragma unroll
     for (int k = 0; k < 4 * IT; ++k) {
       const int e = lane + 64 * k, q = e / (4 * IT), pc = e % (4 * IT);
       const long p = pb + q;
-      sx[k] = p < p1 ? *reinterpret_cast<const uint4*>(X + p * a.I + i0 + pc * 8) : make_uint4(0, 0, 0, 0);
+      sx[k] = *reinterpret_cast<const uint4*>(X + (p < p1 ? p : p0) * a.I + i0 + pc * 8);
     }
+    // (positions past the range were read from the range's first position; they are zeroed here, after all loads were issued)
+#pragma unroll
+    for (int k = 0; k < 4 * OT; ++k) if (pb + (lane + 64 * k) / (4 * OT) >= p1) sdy[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4 * IT; ++k) if (pb + (lane + 64 * k) / (4 * IT) >= p1) sx[k] = make_uint4(0, 0, 0, 0);
   };
   auto store = [&]() {
 #pragma unroll
@@ -163,14 +168,23 @@ __global__ __launch_bounds__(256) void lwg_f32_kernel(LwgArgs a) {
   const long pa = p0 + (u0 << 6), pe = (p0 + (u1 << 6)) < p1 ? (p0 + (u1 << 6)) : p1;
   for (long pb = pa + 8 * wave; pb < pe; pb += 32) {
     float dv[4][OT], xv[4][IT];
+    bool okm[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                              // loads from clamped addresses first, masks afterwards (a `cond ? load : 0`
+      const long p = pb + 2 * s + h;                           //  form serialises the loads behind one another)
+      okm[s] = p < pe;
+      const long pc = okm[s] ? p : pa;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) dv[s][t] = DY[pc * a.O + o0 + 32 * t + r];
+#pragma unroll
+      for (int v = 0; v < IT; ++v) xv[s][v] = X[pc * a.I + i0 + 32 * v + r];
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const long p = pb + 2 * s + h;
-      const bool ok = p < pe;
 #pragma unroll
-      for (int t = 0; t < OT; ++t) dv[s][t] = ok ? DY[p * a.O + o0 + 32 * t + r] : 0.f;
+      for (int t = 0; t < OT; ++t) dv[s][t] = okm[s] ? dv[s][t] : 0.f;
 #pragma unroll
-      for (int v = 0; v < IT; ++v) xv[s][v] = ok ? X[p * a.I + i0 + 32 * v + r] : 0.f;
+      for (int v = 0; v < IT; ++v) xv[s][v] = okm[s] ? xv[s][v] : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
