@@ -48,34 +48,47 @@ __global__ __launch_bounds__(128) void mlin_fwd_kernel(MLArgs a) {
     a.y[l][(long)r * O + o] = acc;
   }
 }
-// grid (row); thread = input channel; walks all layers
-__global__ __launch_bounds__(128) void mlin_dgrad_kernel(MLArgs a, float* dx) {
-  extern __shared__ float sd[];
+// grid (row); 256 threads = 4 slices of the (layer, output) list x 64 input channels each (I <= 256: up to 4 channels per thread);
+// the slices meet in LDS.  Weight loads are issued 8 at a time (one at a time the loop ran at one L2 latency per term).
+__global__ __launch_bounds__(256) void mlin_dgrad_kernel(MLArgs a, float* dx) {
+  extern __shared__ float sd[];                              // [sum of O over the layers] dy of this row, then [4][I] partial sums
   const int r = blockIdx.x;
   const int g = ml_group(a, r);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};                       // I <= 4 * blockDim.x
+  const int slice = threadIdx.x >> 6, il = threadIdx.x & 63;
+  int tot = 0;
   for (int l = 0; l < a.L; ++l) {
-    const int O = a.O[l];
-    __syncthreads();
-    for (int o = threadIdx.x; o < O; o += blockDim.x) sd[o] = a.dy[l][(long)r * O + o];
-    __syncthreads();
-    if (g < 0) continue;
-    const float* wl = a.w[l] + (long)g * O * a.Ipad;
+    for (int o = threadIdx.x; o < a.O[l]; o += 256) sd[tot + o] = a.dy[l][(long)r * a.O[l] + o];
+    tot += a.O[l];
+  }
+  __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g >= 0) {
+    int base = 0;
+    for (int l = 0; l < a.L; ++l) {
+      const int O = a.O[l];
+      const float* wl = a.w[l] + (long)g * O * a.Ipad;
+      for (int o0 = slice * 8; o0 < O; o0 += 32) {             // this slice's outputs of the layer, 8 at a time
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = threadIdx.x + k * blockDim.x;
-      if (i < a.I) {
-        float s = 0.f;
-        for (int o = 0; o < O; ++o) s += sd[o] * wl[(long)o * a.Ipad + i];
-        acc[k] += s;
+        for (int k = 0; k < 4; ++k) {
+          const int i = il + 64 * k;
+          if (i < a.I) {
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = wl[(long)(o0 + j < O ? o0 + j : O - 1) * a.Ipad + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k] += (o0 + j < O ? sd[base + o0 + j] : 0.f) * wv[j];
+          }
+        }
       }
+      base += O;
     }
   }
+  float* part = sd + tot;
+  __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
-    if (i < a.I) dx[(long)r * a.I + i] = acc[k];
-  }
+  for (int k = 0; k < 4; ++k) { const int i = il + 64 * k; if (i < a.I) part[slice * a.I + i] = acc[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.I; i += 256) dx[(long)r * a.I + i] = part[i] + part[a.I + i] + part[2 * a.I + i] + part[3 * a.I + i];
 }
 // grid (o-tile of 4 rows, layer, group); thread = input channel i (x4 output rows per block); walks the group's rows
 __global__ __launch_bounds__(256) void mlin_wgrad_kernel(MLArgs a) {
@@ -83,13 +96,26 @@ __global__ __launch_bounds__(256) void mlin_wgrad_kernel(MLArgs a) {
   const int o0 = blockIdx.x * 4;
   if (o0 >= O || !a.G[l][g]) return;
   const int r0 = a.seg ? a.seg[g] : 0, r1 = a.seg ? a.seg[g + 1] : a.R;
+  int ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ok[k] = o0 + k < O ? o0 + k : O - 1;          // clamped: loads stay unconditional
   for (int i = threadIdx.x; i < a.I; i += blockDim.x) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < r1; ++r) {
-      const float xv = a.x[(long)r * a.I + i];
-      const float* d = a.dy[l] + (long)r * O + o0;
+    for (int rb = r0; rb < r1; rb += 8) {                        // 8 rows per trip, all loads first
+      float xv[8], dv[8][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (o0 + k < O) acc[k] += d[k] * xv;
+      for (int j = 0; j < 8; ++j) {
+        const int r = rb + j < r1 ? rb + j : r1 - 1;
+        xv[j] = a.x[(long)r * a.I + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dv[j][k] = a.dy[l][(long)r * O + ok[k]];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (rb + j < r1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += dv[j][k] * xv[j];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (o0 + k < O) a.G[l][g][(long)(o0 + k) * a.I + i] += acc[k];
@@ -131,7 +157,10 @@ int hdmoe_mlinear_dgrad(float* dx, const float* const* dy, const float* const* w
   int maxO = 0;
   for (int l = 0; l < L; ++l) { if (!dy[l]) return HDMOE_EINVAL; a.dy[l] = dy[l]; if (lens[l] > maxO) maxO = lens[l]; }
   if (R == 0) return HDMOE_OK;
-  hipLaunchKernelGGL(mlin_dgrad_kernel, dim3(R), dim3(128), maxO * sizeof(float), stream, a, dx);
+  int sumO = 0;
+  for (int l = 0; l < L; ++l) sumO += lens[l];
+  if (I > 256) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(mlin_dgrad_kernel, dim3(R), dim3(256), (size_t)(sumO + 4 * I) * sizeof(float), stream, a, dx);
   return hdmoe_launch_status();
 }
 /* G[l * 8 + g] [O[l]][I] += sum over the rows of group g of dy[l]^T . x    (G: host array of L * 8 device pointers, NULL = skip) */

@@ -597,7 +597,7 @@ def multi_linear(x: Tensor, layers, gain: float, *, seg: Optional[Tensor] = None
     L = len(layers)
     bank = _bank.ACTIVE
     ents = None
-    if bank is not None and 1 <= L <= 16 and x.ndim == 2 and x.dtype == torch.float32 and MULTI_LINEAR:
+    if bank is not None and 1 <= L <= 16 and x.ndim == 2 and x.shape[1] <= 256 and x.dtype == torch.float32 and MULTI_LINEAR:
         ents = [bank.lookup(ws, torch.float32, float(gain), 1.0, True) for ws in layers]
         ok = all(e is not None for e in ents) and len({(e.I, e.Ipad, len(e.params)) for e in ents if e is not None}) == 1
         if ok and all(e.khs == [1] * len(e.params) for e in ents) and (seg is not None or len(ents[0].params) == 1):
