@@ -69,7 +69,13 @@ class Stager:
     """Stage bookkeeping shared by the eager warm-up runs and the capture run of a StagedStep.  Model code talks to it through
     ``graph.current()``: ``cut(stage, **tensors_by_producer_stage)`` at a boundary, ``backward(loss)`` instead of loss.backward()."""
 
-    KIND = {"pre": "main", "unet": "u", "vit": "v", "post": "main", "unet_bwd": "u", "vit_bwd": "v", "pre_bwd": "main"}
+    KIND = {"pre": "main", "ur": "r", "unet": "u", "vit": "v", "post": "main", "ucomb_bwd": "u", "ur_bwd": "r", "unet_bwd": "u", "vit_bwd": "v",
+            "pre_bwd": "main"}
+    # SPLIT_ROUTER: the U-Net branch is the longer one, and its router's backward (2.2 ms of kernels) needs nothing from the bank's
+    # backward but the gradient of the routing weights, which the bank's FIRST backward kernel (the combine) produces.  The router
+    # therefore gets its own stream and graphs (`ur`, `ur_bwd`), and the combine backward its own small graph (`ucomb_bwd`) so that
+    # `ur_bwd` can start right after it, beside the bank backward.
+    SPLIT_ROUTER = __import__("os").environ.get("HDMOE_SPLIT_ROUTER", "1") != "0"
 
     def __init__(self, device, streams, pools):
         self.device, self.streams, self.pools = device, streams, pools
@@ -77,7 +83,8 @@ class Stager:
         self.graphs = {}
         self.stage = None
         self._ctx = None
-        self.cuts = {"pre": [], "unet": [], "vit": []}          # producer stage -> [(tensor, detached leaf)]
+        import collections
+        self.cuts = collections.defaultdict(list)                # producer segment -> [(tensor, detached leaf)]
         self.order = []
 
     # -- stage switching ------------------------------------------------------------------------------------------------------
@@ -106,6 +113,10 @@ class Stager:
         are fed to the producer stage's backward section later).  Returns the tensors in keyword order, flattened."""
         self.end()
         self.begin(stage)
+        return self.cut_local(**by_producer)
+
+    def cut_local(self, **by_producer):
+        """Detached leaves without a stage switch: a boundary between two backward sections inside one forward graph."""
         out = []
         for producer, tensors in by_producer.items():
             for t in tensors:
@@ -134,7 +145,12 @@ class Stager:
         try:
             bank.STAGE = "post"
             loss.backward()                                       # fusion + head + loss section; stops at the detached leaves
-            self._section("unet_bwd", "unet")
+            if "ur" in self.order:
+                self._section("ucomb_bwd", "ucomb")               # combine backward: gradients of the bank output rows and of the routing weights
+                self._section("unet_bwd", "unet")
+                self._section("ur_bwd", "ur")
+            else:
+                self._section("unet_bwd", "unet")
             self._section("vit_bwd", "vit")
             self._section("pre_bwd", "pre")
         finally:
@@ -163,13 +179,14 @@ class StagedStep:
     """Drop-in for GraphedStep when ``step_fn`` runs the banked HDMOEM path and calls ``graph.backward(loss)``."""
 
     ORDER = ["pre", "unet", "vit", "post", "unet_bwd", "vit_bwd", "pre_bwd"]
+    ORDER_R = ["pre", "ur", "unet", "vit", "post", "ucomb_bwd", "unet_bwd", "ur_bwd", "vit_bwd", "pre_bwd"]
 
     def __init__(self, step_fn, device, warmup: int = 3):
         self.device = torch.device(device)
         # the U-Net branch is the longer one (the ViT branch has ~2.5 ms of slack in the backward): its stream gets the higher priority
-        prio = {"main": -1, "u": -1, "v": 0} if __import__("os").environ.get("HDMOE_STREAM_PRIO", "1") != "0" else {"main": 0, "u": 0, "v": 0}
-        self.streams = {k: torch.cuda.Stream(device=self.device, priority=prio[k]) for k in ("main", "u", "v")}
-        self.pools = {k: torch.cuda.graph_pool_handle() for k in ("main", "u", "v")}
+        prio = {"main": -1, "u": -1, "v": 0, "r": 0} if __import__("os").environ.get("HDMOE_STREAM_PRIO", "1") != "0" else {"main": 0, "u": 0, "v": 0, "r": 0}
+        self.streams = {k: torch.cuda.Stream(device=self.device, priority=prio[k]) for k in ("main", "u", "v", "r")}
+        self.pools = {k: torch.cuda.graph_pool_handle() for k in ("main", "u", "v", "r")}
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams.values():
             s.wait_stream(cur)
@@ -179,8 +196,9 @@ class StagedStep:
             cur.wait_stream(s)
         torch.cuda.synchronize(self.device)
         st = self._run(step_fn, capture=True)
-        if st.order != self.ORDER:
+        if st.order not in (self.ORDER, self.ORDER_R):
             raise RuntimeError(f"staged step: unexpected stage sequence {st.order}")
+        self.split_router = st.order == self.ORDER_R
         self.graphs = st.graphs
         self._keep = st                                           # boundary tensors live in the graphs' pools
         self.after = {}                                           # {"unet_bwd" | "vit_bwd": callable}: run on that section's stream right after its launch
@@ -222,6 +240,30 @@ class StagedStep:
                 with torch.cuda.stream(stream):
                     fn()
 
+        if self.split_router:
+            r = S["r"]
+            main.wait_stream(cur)
+            run("pre", main)
+            r.wait_stream(main); v.wait_stream(main)
+            run("ur", r)
+            run("vit", v)
+            u.wait_stream(main); u.wait_stream(r)
+            run("unet", u)
+            main.wait_stream(u); main.wait_stream(v)
+            run("post", main)
+            u.wait_stream(main); v.wait_stream(main)
+            run("ucomb_bwd", u)
+            r.wait_stream(u)
+            run("unet_bwd", u)
+            run("ur_bwd", r)
+            run("vit_bwd", v)
+            done("vit_bwd", v)
+            u.wait_stream(r)                                      # the "unet" gradient bucket holds the router's parameters too
+            done("unet_bwd", u)
+            main.wait_stream(u); main.wait_stream(v)
+            run("pre_bwd", main)
+            cur.wait_stream(main)
+            return self.out
         main.wait_stream(cur)
         run("pre", main)
         u.wait_stream(main); v.wait_stream(main)

@@ -29,8 +29,8 @@ VIT_BANK = __import__("os").environ.get("HDMOE_VIT_BANK", "1") != "0"
 
 
 def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_emb: Tensor, text2d: Optional[Tensor],
-                   kcap: Optional[int] = None) -> Tensor:
-    """x channel-last (B,H,W,C) -> (B,H,W,C)."""
+                   kcap: Optional[int] = None, stager=None) -> Tensor:
+    """x channel-last (B,H,W,C) -> (B,H,W,C).  ``stager``: cut the autograd graph between the bank and the combine (staged step)."""
     mods = list(experts)
     E = len(mods)
     if all(isinstance(e, m.Unet_expert) for e in mods) and E <= 8:
@@ -39,6 +39,8 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
         ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg)
+        if stager is not None:
+            (ys,) = stager.cut_local(unet=(ys,))
         return ops.combine_rows(ys, out_router, plan)
     if VIT_BANK and m.vit_bank_compatible(mods, x.shape[1], x.shape[2]):
         plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
@@ -181,16 +183,27 @@ class _HDMOEMBase(nn.Module):
         if st is not None and banked and x.is_cuda:
             # staged step (hdmoe_hip/graph.py): each branch is its own hipGraph on its own stream, cut out of autograd with detached
             # leaves at the two boundaries; the backward sections are driven by Stager.backward
-            te_u, in_u = st.cut("unet", pre=(te, in_unet))
-            (te_r, te_b), (in_r, in_b) = ops.fanout(te_u, 2), ops.fanout(in_u, 2)
-            w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_r, te_r, Unet_router_mask, zeta)
-            out_u = _dispatch_nhwc(ops.cast(in_b, cdt), self.Unet_experts, w_unet, te_b, text2d, kcap=self.top_k)
+            if st.SPLIT_ROUTER:
+                # the U-Net router on its own stream / graphs: its backward then runs beside the bank's (hdmoe_hip/graph.py SPLIT_ROUTER)
+                te_r, in_r = st.cut("ur", pre=(te, in_unet))
+                w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_r, te_r, Unet_router_mask, zeta)
+                te_b, in_b, w_b = st.cut("unet", pre=(te, in_unet), ur=(w_unet,))
+                out_u = _dispatch_nhwc(ops.cast(in_b, cdt), self.Unet_experts, w_b, te_b, text2d, kcap=self.top_k, stager=st)
+            else:
+                te_u, in_u = st.cut("unet", pre=(te, in_unet))
+                (te_r, te_b), (in_r, in_b) = ops.fanout(te_u, 2), ops.fanout(in_u, 2)
+                w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_r, te_r, Unet_router_mask, zeta)
+                out_u = _dispatch_nhwc(ops.cast(in_b, cdt), self.Unet_experts, w_unet, te_b, text2d, kcap=self.top_k)
             te_v, in_v = st.cut("vit", pre=(te, in_vit))
             (te_r, te_b), (in_r, in_b) = ops.fanout(te_v, 2), ops.fanout(in_v, 2)
             w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_r, te_r, Vit_router_mask, zeta)
             out_v = _dispatch_nhwc(ops.cast(in_b, cdt), self.VIT_experts, w_vit, te_b, text2d, kcap=self.top_k)
-            out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
-                "post", unet=(out_u, p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
+            if st.SPLIT_ROUTER:
+                out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
+                    "post", ucomb=(out_u,), ur=(p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
+            else:
+                out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
+                    "post", unet=(out_u, p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
         elif banked and ops.SIDE_STREAMS and x.is_cuda:
             w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_vit, te, Vit_router_mask, zeta)
             fork = torch.cuda.Event()

@@ -1266,7 +1266,7 @@ def test_staged_step_matches_plain_backward():
         finally:
             ops.SIDE_STREAMS = saved
         staged = hgraph.StagedStep(fwd_bwd, DEV, warmup=2)
-        assert sorted(staged.graphs) == sorted(hgraph.StagedStep.ORDER) and hgraph.current() is None
+        assert sorted(staged.graphs) in (sorted(hgraph.StagedStep.ORDER), sorted(hgraph.StagedStep.ORDER_R)) and hgraph.current() is None
         for _ in range(3):
             l_g = staged()
         torch.cuda.synchronize()
