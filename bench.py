@@ -402,7 +402,7 @@ def main():
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
-                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else "hipGraph replay (7 staged graphs, expert branches on 2 streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
+                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
