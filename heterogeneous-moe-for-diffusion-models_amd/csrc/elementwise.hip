@@ -418,6 +418,28 @@ __global__ void patch_relayout_vec_kernel(T* out, const T* in, int H, int W, int
   }
 }
 
+// image -> tokens in PixelShuffle order (f = c*p*p + i*p + j) with the 16-byte vector on the TOKEN side: a thread owns VW consecutive j
+// of one (token, c, i) and gathers them from VW neighbouring pixels (the image-side-vector form above scatters 2-byte stores p*p
+// elements apart: 75 us for 67 MB; this form writes whole vectors).  Needs p % VW == 0.
+template <typename T>
+__global__ void patch_to_tokens_o1_vec_kernel(T* tok, const T* img, int H, int W, int C, int p, int hp, int wp, long nv) {
+  constexpr int VW = VT<T>::W;
+  const int jv = p / VW;                                     // vectors per (c, i) row of a token
+  GRID_STRIDE(v, nv) {
+    long t = v;
+    const int j0 = (int)(t % jv) * VW; t /= jv;
+    const int ii = (int)(t % p); t /= p;
+    const int c = (int)(t % C); t /= C;
+    const int pw = (int)(t % wp); t /= wp;
+    const int ph = (int)(t % hp); const long b = t / hp;
+    const int y = ph * p + ii, x0 = pw * p + j0;
+    alignas(16) T vals[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) vals[k] = (y < H && x0 + k < W) ? img[((b * H + y) * W + x0 + k) * C + c] : from_f<T>(0.f);
+    *reinterpret_cast<uint4*>(tok + v * VW) = *reinterpret_cast<const uint4*>(vals);
+  }
+}
+
 // ---------------------------------------------------------------- small vector-path kernels
 __global__ void fourier_kernel(float* out, const float* x, const float* freqs, const float* phases, int F, long n) {
   GRID_STRIDE(i, n) {                                                  // model_internals.py:171-174
@@ -783,7 +805,7 @@ __global__ void randn_kernel(float* out, uint32_t seed_lo, uint32_t seed_hi, con
 
 // out = sum of up to 16 same-shaped tensors: the backward of a fan-out (a tensor consumed by n layers) in ONE pass -- autograd's own
 // accumulation is n - 1 separate add launches over the same data
-struct SumSrcs { const void* p[16]; };
+struct SumSrcs { const void* p[16]; float sc[16]; };
 template <typename T>
 __global__ void sum_n_kernel(T* out, SumSrcs s, int n, long nv, long nelem) {
   constexpr int W = VT<T>::W;
@@ -791,16 +813,18 @@ __global__ void sum_n_kernel(T* out, SumSrcs s, int n, long nv, long nelem) {
     if ((v + 1) * W <= nelem) {
       float f[W], g[W];
       vload<T>(f, (const T*)s.p[0] + v * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) f[j] *= s.sc[0];
       for (int k = 1; k < n; ++k) {
         vload<T>(g, (const T*)s.p[k] + v * W);
 #pragma unroll
-        for (int j = 0; j < W; ++j) f[j] += g[j];
+        for (int j = 0; j < W; ++j) f[j] += s.sc[k] * g[j];
       }
       vstore<T>(out + v * W, f);
     } else {
       for (long e = v * W; e < nelem; ++e) {
         float f = 0.f;
-        for (int k = 0; k < n; ++k) f += to_f(((const T*)s.p[k])[e]);
+        for (int k = 0; k < n; ++k) f += s.sc[k] * to_f(((const T*)s.p[k])[e]);
         out[e] = from_f<T>(f);
       }
     }
@@ -823,11 +847,11 @@ int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long 
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x) && al16(y)) L1D(axpby_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, (const T*)y, a, b, n / VT<T>::W);
                    else L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
 }
-int hdmoe_sum_n(void* out, const void* const* srcs, int n, long nelem, int dtype, hipStream_t stream) {
+int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int n, long nelem, int dtype, hipStream_t stream) {
   if (!out || !srcs || n < 1 || n > 16) return HDMOE_EINVAL;
   SumSrcs s;
   bool al = al16(out);
-  for (int k = 0; k < 16; ++k) { s.p[k] = srcs[k < n ? k : 0]; al = al && al16(s.p[k]); }
+  for (int k = 0; k < 16; ++k) { s.p[k] = srcs[k < n ? k : 0]; s.sc[k] = (src_scale && k < n) ? src_scale[k] : 1.f; al = al && al16(s.p[k]); }
   if (!al) return HDMOE_EINVAL;
   DT_SWITCH(dtype, L1D(sum_n_kernel<T>, (nelem + VT<T>::W - 1) / VT<T>::W, (T*)out, s, n, (nelem + VT<T>::W - 1) / VT<T>::W, nelem))
 }
@@ -1019,6 +1043,10 @@ int hdmoe_patch_relayout(void* out, const void* in, int N, int H, int W, int C, 
                          int to_img, int dtype, hipStream_t stream) {
   if (hp * p < H || wp * p < W) return HDMOE_EINVAL;
   const long n = (long)N * H * W * C;
+  if (!to_img && order == 1 && al16(out) && (dtype == HDMOE_BF16 || dtype == HDMOE_F32) && p % (dtype == HDMOE_BF16 ? 8 : 4) == 0) {
+    const long nv = (long)N * hp * wp * C * p * p / (dtype == HDMOE_BF16 ? 8 : 4);      // covers the padded tokens too (zeros)
+    DT_SWITCH(dtype, L1D(patch_to_tokens_o1_vec_kernel<T>, nv, (T*)out, (const T*)in, H, W, C, p, hp, wp, nv))
+  }
   if (al16(out) && al16(in) && C % (dtype == HDMOE_BF16 ? 8 : 4) == 0 && (dtype == HDMOE_BF16 || dtype == HDMOE_F32)) {
     const long nv = n / (dtype == HDMOE_BF16 ? 8 : 4);
     if (to_img) { DT_SWITCH(dtype, L1D((patch_relayout_vec_kernel<T, true>), nv, (T*)out, (const T*)in, H, W, C, p, hp, wp, order, nv)) }

@@ -23,7 +23,7 @@ MAX_GROUPS = 8
 # The table is derived from include/hdmoe.h itself, so the binding cannot drift from the declared C ABI.
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "hdmoe.h"))
 _HOST_INT_ARRAYS = {"kh", "kw", "pt", "pl", "lens", "sb", "dims"}
-_HOST_FLOAT_ARRAYS = {"group_lr", "group_wd"}
+_HOST_FLOAT_ARRAYS = {"group_lr", "group_wd", "src_scale"}
 
 
 def _parse_header(path: str) -> dict:

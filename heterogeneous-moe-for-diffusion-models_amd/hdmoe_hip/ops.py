@@ -254,30 +254,33 @@ def _zeros(shape, dtype, device, pool_ok: bool = True) -> Tensor:
 
 class _FanoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, scales):
         ctx.set_materialize_grads(False)
+        ctx.scales = scales
         return tuple(x.view(x.shape) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [_c(g) for g in gs if g is not None]
-        if not gs:
-            return None, None
-        if len(gs) == 1:
-            return gs[0], None
-        out = torch.empty_like(gs[0])
-        for i in range(0, len(gs), 15):                       # 16 sources per launch (the running sum takes one slot)
-            part = gs[i:i + 15] if i == 0 else [out] + gs[i:i + 15]
-            call("hdmoe_sum_n", out, part, len(part), out.numel(), _dt(out))
-        return out, None
+        sc = ctx.scales or (1.0,) * len(gs)
+        pairs = [(_c(g), float(s)) for g, s in zip(gs, sc) if g is not None]
+        if not pairs:
+            return None, None, None
+        if len(pairs) == 1 and pairs[0][1] == 1.0:
+            return pairs[0][0], None, None
+        out = torch.empty_like(pairs[0][0])
+        for i in range(0, len(pairs), 15):                    # 16 sources per launch (the running sum takes one slot)
+            part = pairs[i:i + 15] if i == 0 else [(out, 1.0)] + pairs[i:i + 15]
+            call("hdmoe_sum_n", out, [g for g, _ in part], [s for _, s in part], len(part), out.numel(), _dt(out))
+        return out, None, None
 
 
-def fanout(x: Tensor, n: int):
+def fanout(x: Tensor, n: int, scales=None):
     """n aliases of ``x`` for n consumers: their gradients are summed by ONE kernel in the backward (autograd's own accumulation is
-    n - 1 separate add launches).  The aliases must not be modified in place."""
+    n - 1 separate add launches).  ``scales``: per-alias factors applied to the incoming gradients inside that sum (a consumer that
+    hands back an unscaled gradient, mp_conv(res_grad_raw=True)).  The aliases must not be modified in place."""
     if n <= 1 or not (torch.is_tensor(x) and x.requires_grad):
         return tuple(x for _ in range(max(n, 1)))
-    return _FanoutFn.apply(x, int(n))
+    return _FanoutFn.apply(x, int(n), None if scales is None else tuple(float(v) for v in scales))
 
 
 class _W6Arena:
@@ -740,7 +743,10 @@ class _AxpbyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(g); call("hdmoe_axpby", dx, g, None, a, 0.0, g.numel(), _dt(g))
         if has_y and ctx.needs_input_grad[1]:
-            dy = torch.empty_like(g); call("hdmoe_axpby", dy, g, None, b, 0.0, g.numel(), _dt(g))
+            if dx is not None and a == b:
+                dy = dx                                       # equal weights (mp_sum with t = 0.5): one scaled copy serves both inputs
+            else:
+                dy = torch.empty_like(g); call("hdmoe_axpby", dy, g, None, b, 0.0, g.numel(), _dt(g))
         return dx, dy, None, None
 
 

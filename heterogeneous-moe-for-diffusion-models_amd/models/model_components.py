@@ -432,7 +432,10 @@ def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t, rag, t
     # TMSA: time-modulated self-attention (MP_Attention.forward, reference model_internals.py:338-409)
     at = [b.TMSA for b in blocks]
     a0 = at[0]
-    yq, yk, yv, yr = ops.fanout(y, 4)
+    ab = a0.attn_balance
+    an = ((1.0 - ab) ** 2 + ab ** 2) ** 0.5
+    # (the residual consumers hand back an unscaled gradient -- res_grad_raw -- and the factor is applied inside the fan-out's sum)
+    yq, yk, yv, yr = ops.fanout(y, 4, scales=(1.0, 1.0, 1.0, (1.0 - ab) / an))
     q = lin([a.q_proj for a in at], yq, b0.gain_s)
     k = lin([a.k_proj for a in at], yk, b0.gain_s)
     v = lin([a.v_proj for a in at], yv, b0.gain_s)
@@ -444,14 +447,12 @@ def vit_block_bank_forward(blocks: Sequence["Vit_block"], tok: Tensor, t, rag, t
         k = ops.seq_bcast_add(k, lin([a.k_time for a in at], tk, b0.gain_t))
         v = ops.seq_bcast_add(v, lin([a.v_time for a in at], tv, b0.gain_t))
     o = ops.attention_rag(q, k, v, [a.rel_pos_bias for a in at], rag, a0.num_heads)
-    ab = a0.attn_balance
-    an = ((1.0 - ab) ** 2 + ab ** 2) ** 0.5
-    y = lin([a.out_proj for a in at], o, b0.gain_s, res=yr, alpha=ab / an, beta=(1.0 - ab) / an)
+    y = lin([a.out_proj for a in at], o, b0.gain_s, res=yr, alpha=ab / an, beta=(1.0 - ab) / an, res_grad_raw=True)
     y = ops.mp_sum(y, res_attn, bal)
-    y, yn = ops.fanout(y, 2)
+    y, yn = ops.fanout(y, 2, scales=(bal / n, 1.0))
     h = ops.ln_rag(yn, [b.norm2.weight for b in blocks], [b.norm2.bias for b in blocks], rag, b0.norm2.eps)
     h = ops.mp_silu(lin([b.linear2 for b in blocks], h, b0.gain_s))
-    h = lin([b.linear3 for b in blocks], h, b0.gain_s, res=y, alpha=(1.0 - bal) / n, beta=bal / n)
+    h = lin([b.linear3 for b in blocks], h, b0.gain_s, res=y, alpha=(1.0 - bal) / n, beta=bal / n, res_grad_raw=True)
     if b0.skip_proj is not None:
         return lin([b.skip_proj for b in blocks], res_main, b0.gain_s, res=h, alpha=(1.0 - bal) / n, beta=bal / n)
     return ops.mp_sum(res_main, h, bal)

@@ -100,7 +100,7 @@ int hdmoe_wbank_bwd(const void* descs, const int* rows, int nrows, HS stream);
 
 /* ---- K4/K7: pointwise, broadcast, relayout  (model_internals.py:33-127, model_components.py:232-253) ----- */
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, HS stream);      /* a*x + b*y (y may be NULL) : mp_sum */
-int hdmoe_sum_n(void* out, const void* const* srcs, int n, long nelem, int dtype, HS stream);                  /* sum of n <= 16 tensors (16-byte aligned): fan-out backward */
+int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int n, long nelem, int dtype, HS stream);   /* sum_k src_scale[k] * srcs[k], n <= 16 tensors (16-byte aligned), src_scale = host array or NULL (all 1): fan-out backward */
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, HS stream);                     /* a*x + c */
 int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, HS stream);
 int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
