@@ -738,7 +738,7 @@ __global__ void attn_rag_dbias_kernel(const T* dout, const T* q, const T* k, con
   if (!rg.dbias[g]) return;
   const float bv = rg.bias[g][((long)h * Sb + i) * Sb + j];
   float acc = 0.f;
-  for (int r = rg.seg[g]; r < rg.seg[g + 1]; ++r) {
+  for (int r = rg.seg[g] + (int)blockIdx.y; r < rg.seg[g + 1]; r += (int)gridDim.y) {     // gridDim.y row slices per element (atomic merge)
     const T* qp = q + ((long)r * Sp + i) * E + h * D;
     const T* dop = dout + ((long)r * Sp + i) * E + h * D;
     const T* kp = k + ((long)r * Sp + j) * E + h * D;
@@ -749,7 +749,7 @@ __global__ void attn_rag_dbias_kernel(const T* dout, const T* q, const T* k, con
     const long li = ((long)r * H + h) * Sp + i;
     acc += __expf(s * scale + bv - lse[li]) * (dp - delta[li]);
   }
-  rg.dbias[g][((long)h * Sb + i) * Sb + j] += acc;
+  atomicAdd(&rg.dbias[g][((long)h * Sb + i) * Sb + j], acc);
 }
 
 static inline bool mk_raga(RagA& rg, const int* seg, const int* lens, const int* sb, const float* const* bias, float* const* dbias,
@@ -787,7 +787,7 @@ int attn_rag_bwd_launch(void* dq, void* dk, void* dv, float* delta, const void* 
   hipLaunchKernelGGL((attn_rag_bwd_kernel<T, D>), dim3(R, H), dim3(64), lds, st, (T*)dq, (T*)dk, (T*)dv, delta, (const T*)dout, (const T*)out,
                      (const T*)q, (const T*)k, (const T*)v, lse, rg, Sp, H, scale);
   if (want_dbias)
-    hipLaunchKernelGGL((attn_rag_dbias_kernel<T, D>), dim3(cdiv(rg.off[rg.ng], 256)), dim3(256), 0, st, (const T*)dout, (const T*)q, (const T*)k,
+    hipLaunchKernelGGL((attn_rag_dbias_kernel<T, D>), dim3(cdiv(rg.off[rg.ng], 256), 8), dim3(256), 0, st, (const T*)dout, (const T*)q, (const T*)k,
                        (const T*)v, lse, delta, rg, Sp, H, scale);
   return hdmoe_launch_status();
 }
