@@ -1482,4 +1482,28 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
   return hdmoe_launch_status();
 }
 
+
+/* 3x3 "same" conv of an fp32 tensor as split bf16 (conv6s) with GroupNorm(1, C) + ReLU of the PRODUCING layer applied to x while it is
+ * staged (in_scale / in_shift [N][Cin] from hdmoe_gn1_finalize, or NULL) and per-sample partial statistics of y written to stats_ws
+ * ([N][hdmoe_conv_split_stats_slots][2] floats, or NULL).  w: [hi | lo] bf16 image, wplane elements per plane.  Returns 1 when the shape
+ * is outside the kernel's domain (nothing launched). */
+int hdmoe_conv_split_stats_slots(int H, int W, int Cout) {
+  if (!(W == 16 || W % 32 == 0) || H < 8 || Cout % 32) return 0;
+  const int TW = W >= 32 ? 32 : 16, TH = 256 / TW;
+  const int tpi = (W / TW) * (int)cdiv(H, TH);
+  return tpi * (Cout / (Cout % 64 == 0 ? 64 : 32)) * 4;
+}
+int hdmoe_conv_fwd_split_gn(const void* x, const void* w, void* y, const float* in_scale, const float* in_shift, int in_relu, float* stats_ws,
+                            long wstride, long wplane, int N, int H, int W, int Cin, int Cout, float alpha, hipStream_t stream) {
+  if (!x || !w || !y || (in_scale == nullptr) != (in_shift == nullptr)) return HDMOE_EINVAL;
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.res = nullptr; a.seg = nullptr; a.wstride = wstride;
+  a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cin = Cin; a.Cphys = Cin; a.Ipad = Cin; a.Cout = Cout; a.Cstore = Cout;
+  a.stride = 1; a.ones = 0; a.ngroups = 1; a.alpha = alpha; a.beta = 0.f; a.n0 = 0;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.kh[g] = 3; a.kw[g] = 3; a.pt[g] = 1; a.pl[g] = 1; }
+  ConvFuse f;
+  f.in_scale = in_scale; f.in_shift = in_shift; f.in_relu = in_relu; f.stats = stats_ws;
+  return conv6_split_try_launch(a, wplane, &f, stream);
+}
+
 }  // extern "C"

@@ -8,7 +8,7 @@ struct C6SArgs {
   C6Args c;
   int wplane;                         // bytes between the hi and the lo weight image
   const float* in_scale; const float* in_shift; int in_relu;   // fused input transform (or null)
-  float* stats;                       // [N][2] fp32 accumulators (sum, sum of squares of the outputs), or null
+  float* stats;                       // [N][tpi * nblk * 4][2] fp32 partial (sum, sum of squares) of the outputs per sample, or null
 };
 struct C6SPlan { C6SArgs sa; int NT; unsigned G; size_t lds; };
 struct ConvFuse;
@@ -305,9 +305,16 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
             }
           }
       }
-      if (sa.stats) {                                               // both tiles of a wave's blocks belong to one sample
+      if (sa.stats) {
+        // both tiles of a wave's blocks belong to one sample.  One (sum, sum of squares) slot per (tile of the image, channel block,
+        // wave of the tile): every slot is written exactly once per launch, the consumer (hdmoe_gn1_finalize) adds the slots of a
+        // sample in a fixed order -- no atomics, a sample's statistics do not depend on its batch.
         s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0 && tv) { atomicAdd(sa.stats + 2 * (long)n, s1); atomicAdd(sa.stats + 2 * (long)n + 1, s2); }
+        if (lane == 0 && tv) {
+          const int ti = (ty0 >> (8 - a.tws)) * a.tiles_x + (tx0 >> a.tws);
+          const long slot = ((long)n * a.tpi + ti) * a.nblk * 4 + cur.nbk * 4 + (wave & 3);
+          sa.stats[2 * slot] = s1; sa.stats[2 * slot + 1] = s2;
+        }
       }
     }
     if (!has_next) break;

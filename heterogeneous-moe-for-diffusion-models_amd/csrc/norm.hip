@@ -617,6 +617,58 @@ template <typename T> static inline bool gn_vec_ok(int C, int G, const void* a, 
   else if ((dtype) == HDMOE_BF16) { using T = bf16; CALL; } \
   else return HDMOE_EDTYPE;
 
+// ---------------------------------------------------------------- GroupNorm(1, C) fused into the neighbouring convs (router trunks)
+// Router.hard_route is conv -> GroupNorm(1, C) -> ReLU three times, then AdaptiveAvgPool2d(1) (reference model_components.py:100-112).
+// The split-bf16 conv kernel leaves per-sample partial (sum, sum of squares) slots of its OUTPUT (conv6s_body.h); this kernel turns
+// them into mean / rstd and the per-(sample, channel) affine  scale = gamma * rstd, shift = beta - mean * rstd * gamma  that the NEXT
+// conv (and its weight gradient) apply to the tensor while staging it: the normalised activation is never written.
+namespace {
+__global__ void gn1_finalize_kernel(float* scale, float* shift, float* mean, float* rstd, const float* ws, const float* gamma, const float* beta,
+                                    int slots, int C, float inv_count, float eps) {
+  __shared__ float sm[2];
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double s1 = 0.0, s2 = 0.0;                                  // fixed order; fp64 for the few dozen partials (the cancellation in E[y^2] - mean^2)
+    for (int k = 0; k < slots; ++k) { s1 += ws[((long)n * slots + k) * 2]; s2 += ws[((long)n * slots + k) * 2 + 1]; }
+    const double m = s1 * inv_count;
+    double var = s2 * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    sm[0] = (float)m; sm[1] = (float)(1.0 / sqrt(var + (double)eps));
+    mean[n] = sm[0]; rstd[n] = sm[1];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float g = gamma[c] * sm[1];
+    scale[(long)n * C + c] = g;
+    shift[(long)n * C + c] = beta[c] - sm[0] * g;
+  }
+}
+// out[n][c] = mean over the S positions of relu(y[n][s][c] * scale[n][c] + shift[n][c]): the last GroupNorm + ReLU + average pool of the
+// trunk in one read of y (fixed summation order)
+__global__ __launch_bounds__(256) void gn1_relu_mean_kernel(float* out, const float* y, const float* scale, const float* shift, long S, int C) {
+  extern __shared__ float part[];                              // [256 / C4][C]
+  const int n = blockIdx.x, C4 = C / 4, rows = 256 / C4;
+  const int cq = threadIdx.x % C4, rw = threadIdx.x / C4;
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  f4 acc = (f4)(0.f);
+  if (rw < rows) {
+    const f4 sc = *reinterpret_cast<const f4*>(scale + (long)n * C + 4 * cq), sh = *reinterpret_cast<const f4*>(shift + (long)n * C + 4 * cq);
+    for (long s2 = rw; s2 < S; s2 += rows) {
+      const f4 v = *reinterpret_cast<const f4*>(y + ((long)n * S + s2) * C + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += fmaxf(v[e] * sc[e] + sh[e], 0.f);
+    }
+    *reinterpret_cast<f4*>(part + (long)rw * C + 4 * cq) = acc;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int k = 0; k < rows; ++k) t += part[(long)k * C + c];
+    out[(long)n * C + c] = t / (float)S;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int hdmoe_pixelnorm_fwd(void* xn, void* h, const void* x, long rows, int C, int dtype, hipStream_t stream) {
@@ -729,6 +781,22 @@ int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, c
   if (g > 256) g = 256;
   DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(g), dim3(TPB), 2 * C * sizeof(float), stream, (T*)dx, dgamma, dbeta,
                                       (const T*)dy, (const T*)x, gamma, mean, rstd, C, rows))
+  return hdmoe_launch_status();
+}
+
+
+/* partial slots [N][slots][2] of a conv output (hdmoe_conv_fwd_split_gn) -> mean / rstd [N] and scale / shift [N][C] of GroupNorm(1, C) */
+int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, const float* ws, const float* gamma, const float* beta, int N,
+                       int slots, int C, long count, float eps, hipStream_t stream) {
+  if (!scale || !shift || !mean || !rstd || !ws || !gamma || !beta || N < 1 || slots < 1 || C < 1 || count < 1) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(gn1_finalize_kernel, dim3(N), dim3(128), 0, stream, scale, shift, mean, rstd, ws, gamma, beta, slots, C, 1.f / (float)count, eps);
+  return hdmoe_launch_status();
+}
+/* out [N][C] = mean_s relu(y [N][S][C] * scale [N][C] + shift [N][C])   (fp32; C % 4 == 0, C <= 1024) */
+int hdmoe_gn1_relu_mean(float* out, const float* y, const float* scale, const float* shift, int N, long S, int C, hipStream_t stream) {
+  if (!out || !y || !scale || !shift || N < 1 || S < 1 || C < 4 || C % 4 || C > 1024) return HDMOE_EINVAL;
+  const int rows = 256 / (C / 4);
+  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(256), (size_t)rows * C * sizeof(float), stream, out, y, scale, shift, S, C);
   return hdmoe_launch_status();
 }
 

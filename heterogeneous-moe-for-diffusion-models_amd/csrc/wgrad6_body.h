@@ -12,6 +12,9 @@ struct W6Args {
   int upw, chunks;
   int xbytes, dybytes;
   long ws_item;                       // floats of one partial slab (taps * Cout * Cin)
+  // SPLIT only: the x operand is relu(x * in_scale[n][c] + in_shift[n][c]) (GroupNorm(1, C) + ReLU of the producing layer applied while
+  // the tile is staged -- the normalised activation is never materialised; padding pixels stay zero).  Null = plain x.
+  const float* in_scale; const float* in_shift; int in_relu;
 };
 struct W6DualPlan { W6Args c[2]; int ibs, obs, TWS, OT; size_t lds; };
 // Launch geometry of the deferred dual-class bf16 weight gradient of one layer (wgrad6.hip).  0 = planned, 1 = not applicable.
@@ -78,6 +81,16 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
       const bool ok = px < HWp * HHp && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + i0) * 4 + cqx * 16) : 0xFFFFFFFFu;
       sxr[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      if (a.in_scale) {                                       // (wave-uniform branch)
+        const f4 sc = *reinterpret_cast<const f4*>(a.in_scale + (long)n * a.Cin + i0 + cqx * 4);
+        const f4 sh = *reinterpret_cast<const f4*>(a.in_shift + (long)n * a.Cin + i0 + cqx * 4);
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          float v = sxr[k][e2] * sc[e2] + sh[e2];
+          if (a.in_relu) v = fmaxf(v, 0.f);
+          sxr[k][e2] = ok ? v : 0.f;
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < NDS; ++k) {

@@ -448,7 +448,7 @@ class _MPConvFn(torch.autograd.Function):
                 Opad = (O + 15) // 16 * 16
                 wdstride = 9 * I * Opad
                 if call("hdmoe_conv_bwd6s", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, G * wdstride, N, H, W, I, O, khs, kws, pts, pts,
-                        alpha, ws, ws.numel() * 4) == 0:
+                        alpha, ws, ws.numel() * 4, None, None, 0) == 0:
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, F32S, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
@@ -1563,6 +1563,119 @@ ACT_NONE, ACT_RELU, ACT_MP_SILU = 0, 1, 2
 def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, act: int = ACT_NONE, eps: float = 1e-5) -> Tensor:
     """nn.GroupNorm over a channel-last tensor (N, ..., C), optionally fused with ReLU / mp_silu."""
     return _GroupNormFn.apply(x, gamma, beta, int(groups), int(act), float(eps))
+
+
+TRUNK_FUSED = _os.environ.get("HDMOE_TRUNK_FUSED", "1") != "0"
+
+
+class _TrunkFn(torch.autograd.Function):
+    """Router.hard_route up to the average pool (reference model_components.py:100-112): three [MP_Conv 3x3 -> GroupNorm(1, C) -> ReLU]
+    and AdaptiveAvgPool2d(1) over an fp32 channel-last tensor, with the GroupNorm + ReLU folded into the convs on either side
+    (split-bf16 arithmetic, csrc/conv6s.hip):
+      conv_l writes y_l and per-sample partial statistics of y_l -> hdmoe_gn1_finalize -> scale_l / shift_l [N][C];
+      conv_{l+1} (and, in the backward, its weight gradient) stage relu(y_l * scale_l + shift_l) instead of a stored activation;
+      the last GroupNorm + ReLU + pool is one read of y_3 (hdmoe_gn1_relu_mean).
+    The normalised activations are never written.  ``tensors`` = (weight, gamma, beta) x 3; ``ents`` the ready weight-bank entries."""
+
+    @staticmethod
+    def forward(ctx, x, ents, bank, eps, *tensors):
+        from ._lib import lib
+        x = _c(x)
+        N, H, W, _ = x.shape
+        S = H * W
+        inp, sc, sh = x, None, None
+        saved = []
+        for l in range(3):
+            w, gamma, beta = tensors[3 * l:3 * l + 3]
+            O, I = int(w.shape[0]), int(w.shape[1])
+            ent = ents[l]
+            slots = lib().hdmoe_conv_split_stats_slots(H, W, O)
+            y = torch.empty((N, H, W, O), dtype=torch.float32, device=x.device)
+            ws = torch.empty((N, max(slots, 1), 2), dtype=torch.float32, device=x.device)
+            if slots < 1 or call("hdmoe_conv_fwd_split_gn", inp, ent.wf, y, sc, sh, 1, ws, ent.wstride, ent.wstride, N, H, W, I, O, 1.0) != 0:
+                raise RuntimeError("router trunk: layer outside the split conv kernel's domain (ops.trunk_ok should have said so)")
+            sc = torch.empty((N, O), dtype=torch.float32, device=x.device)
+            sh = torch.empty_like(sc)
+            mean = torch.empty(N, dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            call("hdmoe_gn1_finalize", sc, sh, mean, rstd, ws, gamma, beta, N, slots, O, S * O, eps[l])
+            saved += [y, sc, sh, mean, rstd]
+            inp = y
+        out = torch.empty((N, O), dtype=torch.float32, device=x.device)
+        call("hdmoe_gn1_relu_mean", out, inp, sc, sh, N, S, O)
+        ctx.save_for_backward(x, *saved, *tensors)
+        ctx.ents, ctx.bank = ents, bank
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import lib, _int_array
+        import ctypes
+        x, *rest = ctx.saved_tensors
+        saved, tensors = rest[:15], rest[15:]
+        N, H, W, _ = x.shape
+        S = H * W
+        ents, bank = ctx.ents, ctx.bank
+        params = [t for l in range(3) for t in tensors[3 * l + 1:3 * l + 3]]
+        bufs, ret = _param_grads(params)
+        # d(mean over S of a_3) -> every position of a_3
+        O3 = int(tensors[6].shape[0])
+        da = torch.empty((N, H, W, O3), dtype=torch.float32, device=x.device)
+        call("hdmoe_seq_bcast_add", da, None, _c(g), N, S, O3, 1.0 / S, 0)
+        k3 = ctypes.cast(_int_array([3]), ctypes.c_void_p)
+        for l in (2, 1, 0):
+            w, gamma, beta = tensors[3 * l:3 * l + 3]
+            y, sc, sh, mean, rstd = saved[5 * l:5 * l + 5]
+            O, I = int(w.shape[0]), int(w.shape[1])
+            dy = torch.empty_like(y)
+            ws = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+            call("hdmoe_groupnorm_bwd", dy, bufs[2 * l], bufs[2 * l + 1], ws, da, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
+            ent = ents[l]
+            kib = lib().hdmoe_conv_wgrad6_ws_kib(1, N, H, W, I, O, k3, k3, F32S)
+            arena = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
+            if arena is None:
+                raise RuntimeError("router trunk backward: no weight-gradient workspace (HDMOE_W6_ARENA_MB too small?)")
+            xin = x if l == 0 else saved[5 * (l - 1)]
+            isc, ish = (None, None) if l == 0 else (saved[5 * (l - 1) + 1], saved[5 * (l - 1) + 2])
+            da = torch.empty_like(xin)
+            wdstride = 9 * I * ((O + 15) // 16 * 16)
+            if call("hdmoe_conv_bwd6s", xin, dy, ent.wd, da, list(ent.G), None, 1, wdstride, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
+                    arena, arena.numel() * 4, isc, ish, 1) != 0:
+                raise RuntimeError("router trunk backward: layer outside the fused backward kernel's domain")
+            bank.defer_w6(list(ent.G), None, arena, [1, N, H, W, I, O, F32S, 0, 3, 0, 0, 0, 0, 0, 0, 0])
+            bank.note_backward(ent)
+        out = [da, None, None, None]
+        for l in range(3):
+            out += [None, ret[2 * l], ret[2 * l + 1]]
+        return tuple(out)
+
+
+def trunk_ok(x: Tensor, convs) -> bool:
+    """Can Router.hard_route take the fused path?  bf16 compute mode with split-bf16 trunks, every conv a ready weight-bank entry inside the
+    split kernels' domain, and the deferred weight-gradient path on."""
+    if not (TRUNK_FUSED and ROUTER_SPLIT and BWD6 and W6_DEFER and PROFILE is None and _bank.ACTIVE is not None):
+        return False
+    if x.dtype != torch.float32 or x.ndim != 4:
+        return False
+    c = x.shape[-1]
+    for w in convs:
+        probe = torch.empty((1, x.shape[1], x.shape[2], c), dtype=torch.float32, device="meta")
+        if not _split_ok(probe, [w], False) or int(w.shape[1]) != c:
+            return False
+        c = int(w.shape[0])
+    return c % 4 == 0 and c <= 1024
+
+
+def router_trunk(x: Tensor, convs, norms) -> Optional[Tensor]:
+    """Fused Router.hard_route[0:10] -> (N, 4C) fp32, or None when the weight bank has not prepared the layers yet (the caller then
+    runs the layers one by one; the lookup registers them for the next step)."""
+    ents = [_bank.ACTIVE.lookup([w], "split", 1.0, 1.0, True) for w in convs]
+    if any(e is None for e in ents):
+        return None
+    tensors = []
+    for w, nm in zip(convs, norms):
+        tensors += [w, nm.weight, nm.bias]
+    return _TrunkFn.apply(x, ents, _bank.ACTIVE, [float(nm.eps) for nm in norms], *tensors)
 
 
 class _LayerNormFn(torch.autograd.Function):

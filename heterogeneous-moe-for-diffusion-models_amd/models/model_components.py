@@ -82,9 +82,16 @@ class Router(nn.Module):
         # in the trunk gradients at the fp32 tests' 3e-4 tolerance.
         import hdmoe_hip
         split = ops.ROUTER_SPLIT and hdmoe_hip.compute_dtype() == torch.bfloat16
-        for ci, gi in ((0, 1), (3, 4), (6, 7)):
-            x = ops.group_norm(hr[ci]._fwd(x, split=split), hr[gi].weight, hr[gi].bias, 1, ops.ACT_RELU, hr[gi].eps)
-        x = ops.seq_mean(x)                                             # AdaptiveAvgPool2d(1) -> fp32 (B, 4C)
+        pooled = None
+        convs = [hr[0].weights, hr[3].weights, hr[6].weights]
+        if split and ops.trunk_ok(x, convs):
+            # GroupNorm + ReLU folded into the neighbouring convs; None until the weight bank has prepared the layers (first step)
+            pooled = ops.router_trunk(x, convs, [hr[1], hr[4], hr[7]])
+        if pooled is None:
+            for ci, gi in ((0, 1), (3, 4), (6, 7)):
+                x = ops.group_norm(hr[ci]._fwd(x, split=split), hr[gi].weight, hr[gi].bias, 1, ops.ACT_RELU, hr[gi].eps)
+            pooled = ops.seq_mean(x)                                    # AdaptiveAvgPool2d(1) -> fp32 (B, 4C)
+        x = pooled
         x = ops.dropout(x, hr[10].p, self.training)
         if time_emb.ndim == 3:
             time_emb = time_emb.squeeze(1)

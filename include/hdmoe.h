@@ -84,7 +84,18 @@ int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, flo
                     const int* pl, float alpha, void* ws, long ws_bytes, int dtype, HS stream);
 int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups,
                      long wd_stride, long wd_plane, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw,
-                     const int* pt, const int* pl, float alpha, void* ws, long ws_bytes, HS stream);   /* fp32 tensors, split bf16 (3x3) */
+                     const int* pt, const int* pl, float alpha, void* ws, long ws_bytes, const float* in_scale, const float* in_shift,
+                     int in_relu, HS stream);   /* fp32 tensors, split bf16 (3x3); in_scale / in_shift (or NULL): x is relu(x * scale[n][c] + shift[n][c]) */
+/* GroupNorm(1, C) + ReLU of the router trunks fused into the neighbouring convs (model_components.py:100-112): the conv writes per-sample
+ * partial statistics of its output, hdmoe_gn1_finalize turns them into mean / rstd and a per-(sample, channel) scale / shift, the NEXT
+ * conv (and its weight gradient, hdmoe_conv_bwd6s) apply relu(x * scale + shift) while staging x, hdmoe_gn1_relu_mean is the last
+ * GroupNorm + ReLU + AdaptiveAvgPool2d(1). */
+int hdmoe_conv_fwd_split_gn(const void* x, const void* w, void* y, const float* in_scale, const float* in_shift, int in_relu,
+                            float* stats_ws, long wstride, long wplane, int N, int H, int W, int Cin, int Cout, float alpha, HS stream);
+int hdmoe_conv_split_stats_slots(int H, int W, int Cout);   /* partial-statistics slots per sample of hdmoe_conv_fwd_split_gn (0: outside its domain) */
+int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, const float* ws, const float* gamma, const float* beta,
+                       int N, int slots, int C, long count, float eps, HS stream);
+int hdmoe_gn1_relu_mean(float* out, const float* y, const float* scale, const float* shift, int N, long S, int C, HS stream);
 int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, HS stream);
 
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps

@@ -1165,6 +1165,56 @@ def test_multi_linear_matches_the_per_layer_path(G, R, I, Os, four_d):
         close_scaled(a, b, 5e-6, msg=f"dw[{k}]", atol=1e-6 * gmax)
 
 
+@pytest.mark.parametrize("N,H,C,k", [(5, 32, 32, 2), (3, 16, 32, 1), (9, 64, 32, 1)])
+def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k):
+    """Router.hard_route with GroupNorm(1, C) + ReLU folded into the neighbouring split-bf16 convs (ops.router_trunk: statistics from the
+    conv epilogue, the affine + ReLU applied while the next conv / weight gradient stage the tensor, pooled read at the end) against the
+    layer-by-layer path (conv, GroupNorm kernel, seq_mean -- pinned to the reference by the router golden vectors): logits, top-k
+    indices (bit-exact), input and parameter gradients; and a sample's logits must not depend on its batch."""
+    import hdmoe_hip
+    import models.model_components as mc
+    from hdmoe_hip import ops, bank as wbank
+    torch.manual_seed(4)
+    r = mc.Router(in_channels=C, time_dim=16, top_k=k, num_experts=5).to(DEV)
+    with torch.no_grad():
+        for nm in (r.hard_route[1], r.hard_route[4], r.hard_route[7]):
+            nm.weight.uniform_(0.5, 1.5); nm.bias.uniform_(-0.3, 0.3)
+    r.eval()
+    x = torch.randn(N, C, H, H, device=DEV)
+    te = torch.randn(N, 16, device=DEV)
+    prev = hdmoe_hip.compute_dtype()
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    res = {}
+    try:
+        for mode in ("warm", "layers", "fused", "fused_sub"):
+            ops.TRUNK_FUSED = mode.startswith("fused")
+            sl = slice(1, 3) if mode == "fused_sub" else slice(None)
+            wbank.bank_for(r).begin_step(False)
+            xx = x[sl].clone().requires_grad_(True)
+            sw, gp, lg = r(x=xx, time_emb=te[sl], zeta=0.0)
+            ((gp ** 2).sum() + (sw * 0.37).sum() + lg.sum() * 0.01).backward()
+            wbank.deactivate()
+            torch.cuda.synchronize()
+            res[mode] = (lg.detach().clone(), xx.grad.clone(), {n: p.grad.clone() for n, p in r.named_parameters() if p.grad is not None})
+            r.zero_grad(set_to_none=False)
+    finally:
+        ops.TRUNK_FUSED = True
+        hdmoe_hip.set_compute_dtype(prev)
+    assert all(e.ready for e in r._hdmoe_bank.entries.values())
+    (l0, dx0, pg0), (l1, dx1, pg1), (l2, _, _) = res["layers"], res["fused"], res["fused_sub"]
+    close_scaled(l1, l0, 2e-5, msg="logits")
+    assert torch.equal(torch.topk(l1, k, dim=-1).indices, torch.topk(l0, k, dim=-1).indices)
+    assert torch.equal(l2, l1[1:3])                                # statistics are summed per sample in a fixed order
+    # (the two paths round scale / shift differently: an activation within ~1e-7 of zero may land on the other side of the ReLU, which
+    #  moves the few input-gradient elements under that pixel's 3x3 footprints by a per cent or so)
+    close_scaled(dx1, dx0, 2e-4, msg="dx", outlier_frac=1e-3)
+    close_scaled(dx1, dx0, 1e-1, msg="dx (all)")
+    assert set(pg0) == set(pg1)
+    for n in pg0:
+        # (H = 64: 4.7M activations per layer, a ReLU flip or two is expected -- one flipped pixel of 37k moves a weight gradient ~1e-3)
+        close_scaled(pg1[n], pg0[n], 2e-4 if H < 64 else 1e-2, msg=n, atol=2e-6 * float(pg0[n].abs().max()) + 1e-9)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_silu_branch_and_cat_silu_match_the_separate_ops(dtype):
     """ops.silu_branch / ops.mp_cat_silu (decoder-block entry: the block input feeds mp_silu and the skip / residual path) against
