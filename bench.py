@@ -243,13 +243,24 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # HDMOE_BENCH_FORCE_DIST=1: run the one-rank job through the process group as well (RCCL with world size 1: every collective, stream
+    # hand-off and launch point of the multi-GPU path executes on a single-GPU box)
+    force_dist = world == 1 and os.environ.get("HDMOE_BENCH_FORCE_DIST", "0") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    multi = world > 1 or force_dist
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if multi and os.environ.get("HDMOE_BENCH_EARLY_BARRIER", "0") == "1":
+        dist.barrier()
 
+    if os.environ.get("HDMOE_BENCH_UAF_PROBE", "0") == "1":
+        torch.cuda.memory._record_memory_history(enabled="all", context="alloc", stacks="python", max_entries=2000000)
     import hdmoe_hip
     from hdmoe_hip.dp import GradBuckets
     import configs as C
@@ -262,7 +273,7 @@ def main():
     lc = C.loss_configs
     crit = U.EDM_LOSS(num_experts=kw["num_experts"], sigma_data=kw["sigma_data"], Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"],
                       z_bal=lc["z_bal"], prior_bal=lc["prior_bal"])
-    buckets = GradBuckets(model, bucket_mb=16.0)            # flat fp32 grad buckets; RCCL all-reduce when world > 1
+    buckets = GradBuckets(model, bucket_mb=16.0, force_collectives=force_dist and os.environ.get("HDMOE_BENCH_NO_FORCE_COLL", "0") != "1")            # flat fp32 grad buckets; RCCL all-reduce when world > 1
     zeta = 0.1
 
     from hdmoe_hip import ops
@@ -300,7 +311,7 @@ def main():
             args.no_graph = True
         buckets.enabled = True
         if graphed is not None:
-            if hasattr(graphed, "after") and world > 1:          # staged step: a branch's bucket goes to RCCL as soon as its backward is launched
+            if hasattr(graphed, "after") and multi and os.environ.get("HDMOE_BENCH_NO_AFTER", "0") != "1":          # staged step: a branch's bucket goes to RCCL as soon as its backward is launched
                 graphed.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
 
             def step():
@@ -308,15 +319,35 @@ def main():
                 buckets.finish()
                 return {"loss": l}
 
+    trace_loss = os.environ.get("HDMOE_BENCH_TRACE_LOSS", "0") == "1"    # diagnostic: the loss of every warm-up step (one sync each)
+    uaf_probe = os.environ.get("HDMOE_BENCH_UAF_PROBE", "0") == "1"      # diagnostic: who owned the small blocks a fresh allocation lands on?
     for _ in range(args.warmup):
-        step()
+        l = step()
+        if trace_loss:
+            print(f"[bench] warm-up loss {float(l['loss']):.6g}", file=sys.stderr)
     torch.cuda.synchronize()
     # the step builds ~4k autograd nodes; CPython's cyclic GC would stall the launch thread for ~10 ms every few steps.
     # Collect now and keep the collector off inside the timed region (tensors are freed by reference counting).
     gc.collect()
     gc.disable()
+    if uaf_probe:
+        snap = torch.cuda.memory._snapshot()
+        events = [e for tr in snap["device_traces"] for e in tr]
+        probes = [torch.full((n,), 255, dtype=torch.uint8, device=device) for n in (1, 8, 64, 512, 513, 1024, 2048, 4096, 8192, 65536) for _ in range(4)]
+        torch.cuda.synchronize()
+        l = step()
+        print(f"[uaf] loss after poisoning the free small blocks: {float(l['loss']):.6g}", file=sys.stderr)
+        seen = set()
+        for t in probes:
+            ptr = t.data_ptr()
+            prev = [e for e in events if e.get("action") == "alloc" and e["addr"] <= ptr < e["addr"] + e["size"]]
+            if prev and ptr not in seen:
+                seen.add(ptr)
+                e = prev[-1]
+                fr = [f"{f['filename'].split('/')[-1]}:{f['line']}:{f['name']}" for f in e.get("frames", []) if "torch/" not in f["filename"]][:8]
+                print(f"[uaf] probe {t.numel()} B at {ptr:#x}: last owner {e['size']} B  <- " + " <- ".join(fr), file=sys.stderr)
     mem0 = torch.cuda.memory_allocated()
-    if world > 1:
+    if multi and os.environ.get("HDMOE_BENCH_SKIP_BARRIER", "0") != "1":
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -327,12 +358,14 @@ def main():
         host_s += time.perf_counter() - h0                   # host time to ENQUEUE a step (no sync inside)
         if args.sync_each_step:
             torch.cuda.synchronize()
+        if trace_loss:
+            print(f"[bench] timed-step loss {float(loss['loss']):.6g}", file=sys.stderr)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -387,7 +420,7 @@ def main():
             cpu = dict(value=round((cb / med) / B, 5), unit="denoise-steps/sec", cores=cores, kind="port",
                        sample=f"CPU oracle, fp32, train-mode (dropout, logit noise) fwd+loss+bwd on B={cb} samples/step, {cores} threads, median of {nst - 1} steps "
                               f"({med:.2f} s/step = {cb / med:.2f} samples/s), scaled to the bench's {B}-sample step")
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         line = {
@@ -402,7 +435,7 @@ def main():
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
-                       + (" + RCCL grad all-reduce" if world > 1 else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
+                       + (" + RCCL grad all-reduce" if multi else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
@@ -410,7 +443,7 @@ def main():
         }
         # value = whole-job throughput: every rank runs one B-sample step per step time (weak scaling) => world / t steps/s
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

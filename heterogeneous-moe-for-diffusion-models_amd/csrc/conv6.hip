@@ -71,8 +71,11 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
   const long tiles = (long)c.N * a.tpi;
   static const int force_mt = getenv("HDMOE_C6_MT") ? atoi(getenv("HDMOE_C6_MT")) : 0;
   static const int force_t = getenv("HDMOE_C6_T") ? atoi(getenv("HDMOE_C6_T")) : 0;
-  const int LDS_CAP = 160 * 1024;
+  static const int wg2_env = getenv("HDMOE_C6_WG2") ? atoi(getenv("HDMOE_C6_WG2")) : 0;
+  const bool wg2 = wg2_env && NT == 1;                       // two co-resident workgroups per CU (<1,1> needs 105 VGPRs: 4 waves / SIMD fit)
+  const int LDS_CAP = wg2 ? 80 * 1024 : 160 * 1024;
   int MT = (tiles * a.nblk >= 4 * 256) ? 2 : 1;             // 512-pixel units only when every CU still gets >= 2 of them
+  if (wg2) MT = 1;
   if (force_mt) MT = force_mt;
   int T = 0;
   for (; MT >= 1; --MT) {
@@ -97,7 +100,8 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
   if (lds > (size_t)LDS_CAP || T * (NB / 16) > 40) return 1;
   long ub = (tiles + MT - 1) / MT + c.ngroups;
   ub *= a.nblk;
-  plan.G = (unsigned)(ub < 256 ? ub : 256);
+  const long gcap = wg2 ? 512 : 256;
+  plan.G = (unsigned)(ub < gcap ? ub : gcap);
   plan.MT = MT; plan.NT = NT; plan.lds = lds;
   return 0;
 }

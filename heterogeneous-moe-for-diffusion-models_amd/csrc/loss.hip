@@ -20,6 +20,13 @@ __global__ void sse_rows_kernel(float* sse, const float* d, const float* t, long
   if (threadIdx.x == 0) atomicAdd(&sse[b], acc);
 }
 
+// (a kernel, not hipMemsetAsync: a memset NODE of a captured hipGraph was observed to stop clearing its target once the process made
+//  another allocation after the capture -- the per-sample sums then accumulated across replays; see DESIGN.md "hipGraph hazards")
+__global__ void zero_f32_kernel(float* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 DEVI float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 // single block: all (B) / (B,E) reductions.  aux[0..2E) = column means of pU | pV (kept for the backward)
@@ -124,7 +131,7 @@ int hdmoe_edm_loss_fwd(float* out, float* aux, float* sse, const float* denoised
                        const float* pU, const float* pV, const float* rU, const float* rV, int B, long L, int E, float unet_bal,
                        float vit_bal, float z_bal, hipStream_t stream) {
   if (B < 1 || B > 65535 || E < 1 || E > 64 || L < 1) return HDMOE_EINVAL;
-  if (hipMemsetAsync(sse, 0, sizeof(float) * B, stream) != hipSuccess) return HDMOE_ELAUNCH;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, sse, B);
   const int chunk = 4096;
   hipLaunchKernelGGL(sse_rows_kernel, dim3(cdiv(L, chunk), B), dim3(256), 0, stream, sse, denoised, target, L, chunk);
   hipLaunchKernelGGL(edm_loss_reduce_kernel, dim3(1), dim3(256), 0, stream, out, aux, sse, log_var, pU, pV, rU, rV, B, L, E, unet_bal,

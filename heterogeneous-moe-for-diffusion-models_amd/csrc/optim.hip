@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const OptDesc* descs, con
   }
 }
 
+__global__ void zero1_kernel(float* p) { p[0] = 0.f; }
+
 }  // namespace
 
 extern "C" {
@@ -68,7 +70,7 @@ extern "C" {
 int hdmoe_opt_desc_bytes(void) { return (int)sizeof(OptDesc); }
 // sumsq (1 float, zeroed here) = sum over all tensors of g^2
 int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, hipStream_t stream) {
-  if (hipMemsetAsync(sumsq, 0, sizeof(float), stream) != hipSuccess) return HDMOE_ELAUNCH;
+  hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, stream, sumsq);      // (a kernel, not a memset: memset nodes of captured hipGraphs proved unreliable, see loss.hip)
   if (nchunks > 0) hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, sumsq, (const OptDesc*)descs, (const int2*)chunks);
   return hdmoe_launch_status();
 }

@@ -37,8 +37,11 @@ class GradBuckets:
             return "unet"
         return "rest"
 
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, force_collectives: bool = False):
+        """``force_collectives``: issue the all-reduces even in a one-rank group (a single-GPU box then exercises the RCCL path:
+        stream hand-off, ReduceOp.AVG, the staged step's launch points)."""
         self.group = process_group
+        self.force = bool(force_collectives)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         named.reverse()                                            # backward produces gradients roughly in this order
@@ -104,7 +107,7 @@ class GradBuckets:
         return hook
 
     def _launch(self, bi):
-        if self.world == 1 or self._works[bi] is not None:
+        if (self.world == 1 and not self.force) or self._works[bi] is not None:
             return
         if self._backend == "nccl":                               # "nccl" is RCCL on ROCm
             self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.AVG, group=self.group, async_op=True)

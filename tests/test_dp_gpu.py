@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,10 @@ def _worker(rank, world, port, q):
     for p in (pkg, os.path.join(pkg, "Utils"), root):
         if p not in sys.path:
             sys.path.insert(0, p)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                                          # RCCL; one rank per device, so world == 1 on this box
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import hdmoe_hip
     from hdmoe_hip import ops, graph as hgraph
     from hdmoe_hip.dp import GradBuckets
@@ -75,7 +78,7 @@ def _worker(rank, world, port, q):
     del ref_model
 
     model = build()
-    buckets = GradBuckets(model)
+    buckets = GradBuckets(model, force_collectives=world == 1)
     assert buckets.tags == ["vit", "unet", "rest"]
     staged = hgraph.StagedStep(step_fn(model, inputs(rank), buckets.zero_grad), dev, warmup=2)
     staged.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
@@ -112,3 +115,20 @@ def test_staged_step_with_bucket_overlap_two_ranks_on_one_gpu():
     for rank, bad, n in got:
         assert not bad, (rank, bad)
         assert n > 400
+
+
+def test_staged_step_through_rccl_with_one_rank():
+    """The RCCL branch of the gradient exchange on hardware: a one-rank "nccl" group (device_id init, ReduceOp.AVG, collectives handed
+    off from the staged step's branch streams between graph replays); the averaged gradients of one rank are that rank's gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, "nccl"))
+    p.start()
+    p.join(420)
+    assert p.exitcode == 0
+    rank, bad, n = q.get(timeout=10)
+    assert not bad, bad
+    assert n > 400

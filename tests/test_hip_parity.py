@@ -1341,6 +1341,18 @@ def test_staged_step_matches_plain_backward():
         t = staged.stage_times()
         assert t["unet"][0] >= t["pre"][1] - 1e-3 and t["post"][0] >= max(t["unet"][1], t["vit"][1]) - 1e-3
         assert t["pre_bwd"][0] >= max(t["unet_bwd"][1], t["vit_bwd"][1]) - 1e-3
+        # Regression (found with a one-rank RCCL group: the barrier's tensor allocation between two replays): a replay must not depend
+        # on what the process allocates and writes after the capture.  The loss kernel used to clear its per-sample sums with
+        # hipMemsetAsync; as a memset NODE of the captured graph that clear stopped working after such an allocation and the sums
+        # accumulated across replays (loss -> its clamp of 50).  The clear is a kernel now (csrc/loss.hip).
+        staged.timing = False
+        junk = [torch.zeros(n, device=DEV) for n in (1, 3, 128, 1000, 5000, 1 << 18)]
+        torch.cuda.synchronize()
+        for _ in range(3):
+            l_again = staged()
+        torch.cuda.synchronize()
+        close(l_again, l_ref, rtol=1e-5, atol=1e-6, msg="loss after an allocation between replays")
+        del junk
 
 
 def test_full_size_batch_independence_and_router_invariants():
