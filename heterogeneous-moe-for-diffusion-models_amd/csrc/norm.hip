@@ -506,7 +506,10 @@ __global__ void groupnorm_apply_vec_kernel(T* y, const T* x, const float* gamma,
 template <typename T>
 __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const T* dy,
                                                                      const T* x, const float* gamma, const float* beta, const float* mean,
-                                                                     const float* rstd, long S, int C, int G, int act, int parts) {
+                                                                     const float* rstd, long S, int C, int G, int act, int parts,
+                                                                     const float* dyb, float dybs) {
+  // dyb (or null): the incoming gradient is dyb[n][c] * dybs at every position (the backward of a mean over the positions) -- read from
+  // the (N, C) tensor instead of a materialised broadcast
   constexpr int W = VT<T>::W;
   __shared__ float part[512], part2[512];
   const int n = blockIdx.x, Cg = C / G, cv = C / W;
@@ -522,10 +525,18 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
 #pragma unroll
   for (int j = 0; j < W; ++j) { gm[j] = gamma[mych + j]; bt[j] = beta[mych + j]; dg[j] = 0.f; db[j] = 0.f; }
   float a1 = 0.f, a2 = 0.f;
+  float gb[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) gb[j] = dyb ? dyb[(long)n * C + mych + j] * dybs : 0.f;
   for (long v = threadIdx.x; v < nv; v += blockDim.x) {
     float f[W], d[W];
     vload<T>(f, x + base + v * W);
-    vload<T>(d, dy + base + v * W);
+    if (dyb) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) d[j] = gb[j];
+    } else {
+      vload<T>(d, dy + base + v * W);
+    }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const float xh = (f[j] - m) * rs;
@@ -554,7 +565,8 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
 }
 template <typename T>
 __global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, const float* gamma, const float* beta, const float* mean,
-                                               const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long nvec) {
+                                               const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long nvec,
+                                               const float* dyb, float dybs) {
   constexpr int W = VT<T>::W;
   const int Cg = C / G, cv = C / W;
   const float invm = 1.f / (float)(S * Cg);
@@ -564,7 +576,12 @@ __global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, c
     const float m = mean[sg], rs = rstd[sg], u = s1[sg], w = s2[sg];
     float f[W], d[W];
     vload<T>(f, x + v * W);
-    vload<T>(d, dy + v * W);
+    if (dyb) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) d[j] = dyb[(row / S) * C + c0 + j] * dybs;
+    } else {
+      vload<T>(d, dy + v * W);
+    }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const float xh = (f[j] - m) * rs;
@@ -726,18 +743,20 @@ int hdmoe_groupnorm_fwd_split(void* y, float* mean, float* rstd, float* ws, int 
 // ws: 2*N*G floats of scratch; dgamma/dbeta accumulate (caller zeroes)
 static int groupnorm_bwd_impl(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x, const float* gamma,
                               const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
-                              int dtype, hipStream_t stream) {
+                              int dtype, hipStream_t stream, const float* dyb = nullptr, float dybs = 1.f) {
   if (gn_check(N, C, G) || parts < 1 || parts > 64) return HDMOE_EINVAL;
+  if (dyb && dy == nullptr) dy = x;                           // (only for the vector-path alignment check; never read)
   const long n = (long)N * S * C;
   float* s1 = ws; float* s2 = ws + (long)N * G;
   DT_SWITCH(dtype, if (gn_vec_ok<T>(C, G, dx, dy, x)) {
     const long nvec = n / VT<T>::W;
     hipLaunchKernelGGL(groupnorm_bwd_stats_vec_kernel<T>, dim3(N, parts), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const T*)dy, (const T*)x,
-                       gamma, beta, mean, rstd, S, C, G, act, parts);
+                       gamma, beta, mean, rstd, S, C, G, act, parts, dyb, dybs);
     hipLaunchKernelGGL(groupnorm_bwd_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
-                       gamma, beta, mean, rstd, s1, s2, S, C, G, act, nvec);
+                       gamma, beta, mean, rstd, s1, s2, S, C, G, act, nvec, dyb, dybs);
     return hdmoe_launch_status();
   })
+  if (dyb) return HDMOE_EINVAL;                               // the broadcast form exists for the vector kernels only
   DT_SWITCH(dtype, {
     hipLaunchKernelGGL(groupnorm_bwd_stats_kernel<T>, dim3(N), dim3(512), 2 * C * sizeof(float), stream, s1, s2, dgamma, dbeta,
                        (const T*)dy, (const T*)x, gamma, beta, mean, rstd, S, C, G, act);
@@ -750,6 +769,14 @@ int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const 
                         const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G, int act,
                         int dtype, hipStream_t stream) {
   return groupnorm_bwd_impl(dx, dgamma, dbeta, ws, 1, dy, x, gamma, beta, mean, rstd, N, S, C, G, act, dtype, stream);
+}
+/* The same with the incoming gradient given as g[n][c] * scale at every position (backward of a mean over the S positions that follows
+ * the norm): nothing of size N*S*C is read but x.  fp32 / bf16 vector shapes only (C % vector width == 0). */
+int hdmoe_groupnorm_bwd_bcast(void* dx, float* dgamma, float* dbeta, float* ws, const float* g, float scale, const void* x,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G,
+                              int act, int dtype, hipStream_t stream) {
+  if (!g) return HDMOE_EINVAL;
+  return groupnorm_bwd_impl(dx, dgamma, dbeta, ws, 1, nullptr, x, gamma, beta, mean, rstd, N, S, C, G, act, dtype, stream, g, scale);
 }
 /* parts > 1: ws (2*N*G floats) must be zeroed by the caller; the row-range blocks add into it */
 int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x,

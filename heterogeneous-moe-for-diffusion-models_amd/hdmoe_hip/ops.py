@@ -1618,18 +1618,18 @@ class _TrunkFn(torch.autograd.Function):
         ents, bank = ctx.ents, ctx.bank
         params = [t for l in range(3) for t in tensors[3 * l + 1:3 * l + 3]]
         bufs, ret = _param_grads(params)
-        # d(mean over S of a_3) -> every position of a_3
-        O3 = int(tensors[6].shape[0])
-        da = torch.empty((N, H, W, O3), dtype=torch.float32, device=x.device)
-        call("hdmoe_seq_bcast_add", da, None, _c(g), N, S, O3, 1.0 / S, 0)
         k3 = ctypes.cast(_int_array([3]), ctypes.c_void_p)
+        da = None
         for l in (2, 1, 0):
             w, gamma, beta = tensors[3 * l:3 * l + 3]
             y, sc, sh, mean, rstd = saved[5 * l:5 * l + 5]
             O, I = int(w.shape[0]), int(w.shape[1])
             dy = torch.empty_like(y)
             ws = torch.empty(2 * N, dtype=torch.float32, device=x.device)
-            call("hdmoe_groupnorm_bwd", dy, bufs[2 * l], bufs[2 * l + 1], ws, da, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
+            if l == 2:      # d(mean over S of a_3): g[n][c] / S at every position, read from the (N, C) tensor (no materialised broadcast)
+                call("hdmoe_groupnorm_bwd_bcast", dy, bufs[2 * l], bufs[2 * l + 1], ws, _f32(g), 1.0 / S, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
+            else:
+                call("hdmoe_groupnorm_bwd", dy, bufs[2 * l], bufs[2 * l + 1], ws, da, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
             ent = ents[l]
             kib = lib().hdmoe_conv_wgrad6_ws_kib(1, N, H, W, I, O, k3, k3, F32S)
             arena = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None

@@ -182,6 +182,9 @@ int hdmoe_groupnorm_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const 
  * merged in a fixed order); bwd ws: 2*N*G floats that the CALLER ZEROES (row-range blocks add into them). */
 int hdmoe_groupnorm_fwd_split(void* y, float* mean, float* rstd, float* ws, int parts, const void* x, const float* gamma,
                               const float* beta, int N, long S, int C, int G, int act, float eps, int dtype, HS stream);
+int hdmoe_groupnorm_bwd_bcast(void* dx, float* dgamma, float* dbeta, float* ws, const float* g, float scale, const void* x,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C, int G,
+                              int act, int dtype, HS stream);   /* incoming gradient = g[n][c] * scale at every position (mean over S follows the norm) */
 int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x,
                               const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
                               int G, int act, int dtype, HS stream);
