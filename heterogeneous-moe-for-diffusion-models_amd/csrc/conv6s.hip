@@ -58,8 +58,10 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   a.hb_bytes = 2 * ppt * 1024;                           // one plane (hi or lo) of the two-tile halo image
   const int LDS_CAP = 160 * 1024;
   int T = 0;
+  const int tab_bytes = (fuse && fuse->in_scale) ? 16 * c.Cin : 0;   // scale / shift table of the fused input transform (conv6s_body.h)
+  if (tab_bytes && c.Cin > 512) return 1;
   for (int t = 9; t >= 3; --t)
-    if (t * (NB / 16) <= 40 && 2 * a.hb_bytes + 2 * t * NB * 64 <= LDS_CAP && (t == 9 || t == 5 || t == 3)) { T = t; break; }
+    if (t * (NB / 16) <= 40 && 2 * a.hb_bytes + 2 * t * NB * 64 + tab_bytes <= LDS_CAP && (t == 9 || t == 5 || t == 3)) { T = t; break; }
   if (!T) return 1;
   a.T = T; a.wb_bytes = T * NB * 64;
   auto recip = [](int d) { return (unsigned)((1ull << 32) / (unsigned)d + 1); };
@@ -68,7 +70,7 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   sa.wplane = (int)(wplane_elems * 2);
   sa.in_scale = fuse ? fuse->in_scale : nullptr; sa.in_shift = fuse ? fuse->in_shift : nullptr; sa.in_relu = fuse ? fuse->in_relu : 0;
   sa.stats = fuse ? fuse->stats : nullptr;
-  const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes;
+  const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes + tab_bytes;
   const long tiles = (long)c.N * a.tpi;
   long ub = ((tiles + 1) / 2 + c.ngroups) * a.nblk;
   plan.G = (unsigned)(ub < 256 ? ub : 256);

@@ -114,6 +114,22 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
     for (int k = 0; k < NHP; ++k)
       if (k < nhp) rh[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ho[k], c * 128, 0));
   };
+  // Fused input transform: scale / shift [Cin] of the unit's two samples live in a small LDS table [scale | shift][tile][Cin] behind the
+  // weight buffers.  Thread q < Cin fetches one 16-byte piece of it together with the unit's first halo chunk (tab_load, inside the
+  // MFMA loop) and writes it right before the barrier that precedes the unit's first halo_store (tab_store); loading the values
+  // inside halo_store put an L2 round trip into every staging step.  One buffer is enough: between a unit's last halo_store and
+  // the next unit's tab_store lie the stage barriers of a whole chunk.
+  const int tab_off = 2 * a.hb_bytes + 2 * a.wb_bytes;
+  f4 tabreg = (f4)(0.f);
+  const int tq_kind = tid >= (a.Cin >> 1) ? 1 : 0, tq_rem = tid - tq_kind * (a.Cin >> 1);
+  const int tq_t = tq_rem >= (a.Cin >> 2) ? 1 : 0, tq_c = (tq_rem - tq_t * (a.Cin >> 2)) * 4;
+  auto tab_load = [&](const C6Unit<MT>& u) {
+    if (sa.in_scale && tid < a.Cin)
+      tabreg = *reinterpret_cast<const f4*>((tq_kind ? sa.in_shift : sa.in_scale) + (long)(tq_t ? u.n[1] : u.n[0]) * a.Cin + tq_c);
+  };
+  auto tab_store = [&]() {
+    if (sa.in_scale && tid < a.Cin) *reinterpret_cast<f4*>(lds + tab_off + ((tq_kind * 2 + tq_t) * a.Cin + tq_c) * 4) = tabreg;
+  };
   // registers -> (input transform) -> hi / lo bf16 -> LDS images (XHI at 0, XLO at hb_bytes), conv6's swizzled [pixel][64 B] layout
   auto halo_store = [&](const C6Unit<MT>& u, const unsigned (&ho)[NHP], int c, const f4 (&rh)[NHP]) {
     const int nhp = nhp_of(u.ppt), npxu = 32 * u.ppt;
@@ -125,10 +141,9 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
       if (pxu >= npxu) continue;                              // (the last half piece may reach past the two-tile image)
       f4 v = rh[k];
       if (sa.in_scale && ho[k] != 0xFFFFFFFFu) {              // padding stays exactly zero (the reference pads AFTER the norm + ReLU)
-        const int ch = c * 32 + cq * 4;
-        const int n = 8 * hp >= u.ppt * 16 ? u.n[1] : u.n[0];  // (a half piece never straddles the two tiles: wave-uniform)
-        const f4 sc = *reinterpret_cast<const f4*>(sa.in_scale + (long)n * a.Cin + ch);
-        const f4 sh = *reinterpret_cast<const f4*>(sa.in_shift + (long)n * a.Cin + ch);
+        const int t1 = 8 * hp >= u.ppt * 16 ? 1 : 0;            // (a half piece never straddles the two tiles: wave-uniform)
+        const f4 sc = *reinterpret_cast<const f4*>(lds + tab_off + (t1 * a.Cin + c * 32 + cq * 4) * 4);
+        const f4 sh = *reinterpret_cast<const f4*>(lds + tab_off + ((2 + t1) * a.Cin + c * 32 + cq * 4) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = v[e] * sc[e] + sh[e]; if (sa.in_relu) v[e] = fmaxf(v[e], 0.f); }
       }
@@ -170,6 +185,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
     for (int k = 0; k < np; ++k) issue_wpiece(sb, k, WB0);
     plan(cur, hoc);
     halo_load(hoc, 0, rh, nhp_of(cur.ppt));
+    if (sa.in_scale) { tab_load(cur); tab_store(); __syncthreads(); }
     halo_store(cur, hoc, 0, rh);
   }
   int sp = 0;
@@ -211,7 +227,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
           }
           // ---- the next halo chunk's fp32 registers: loaded beside the chunk's last stage
           if (last_stage && more) {
-            if (last_chunk) { plan(nu, hoc); halo_load(hoc, 0, rh, nhp_of(nu.ppt)); }   // (cur's own offsets are no longer needed)
+            if (last_chunk) { plan(nu, hoc); halo_load(hoc, 0, rh, nhp_of(nu.ppt)); tab_load(nu); }   // (cur's own offsets are no longer needed)
             else halo_load(hoc, c + 1, rh, nhp_of(cur.ppt));
           }
           auto side = [&](int k) { if (k < NWP && k < nwp) issue_wpiece(nsb, k, wbn); };
@@ -271,6 +287,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
         }
       }
       if (more) {
+        if (last_chunk) tab_store();                                // the next unit's scale / shift table (visible after the barrier)
         __syncthreads();                                            // every wave is done reading this chunk's hi / lo images
         if (last_chunk) halo_store(nu, hoc, 0, rh);
         else halo_store(cur, hoc, c + 1, rh);

@@ -644,9 +644,18 @@ __global__ void gn1_finalize_kernel(float* scale, float* shift, float* mean, flo
                                     int slots, int C, float inv_count, float eps) {
   __shared__ float sm[2];
   const int n = blockIdx.x;
+  // wave 0: lane l takes slots l, l + 64, .. (independent loads), then a fixed-shape shuffle tree -- the order depends on `slots` only,
+  // never on the batch; fp64 for the few dozen partials (the cancellation in E[y^2] - mean^2)
+  double s1 = 0.0, s2 = 0.0;
+  if (threadIdx.x < 64) {
+    for (int k = threadIdx.x; k < slots; k += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(ws + ((long)n * slots + k) * 2);
+      s1 += v.x; s2 += v.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_down(s1, d, 64); s2 += __shfl_down(s2, d, 64); }
+  }
   if (threadIdx.x == 0) {
-    double s1 = 0.0, s2 = 0.0;                                  // fixed order; fp64 for the few dozen partials (the cancellation in E[y^2] - mean^2)
-    for (int k = 0; k < slots; ++k) { s1 += ws[((long)n * slots + k) * 2]; s2 += ws[((long)n * slots + k) * 2 + 1]; }
     const double m = s1 * inv_count;
     double var = s2 * inv_count - m * m;
     if (var < 0.0) var = 0.0;

@@ -71,7 +71,12 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
   constexpr int XQ = 8, DYQ = 8 * OT;                        // pieces per pixel (32 / 32*OT channels)
   constexpr int NXS = (HP16 * 16 * XQ + 511) / 512, NDS = 256 * DYQ / 512;
   f4 sxr[SPLIT ? NXS : 1], sdr[SPLIT ? NDS : 1];
+  // (the input transform is applied in split_store, when the registers are consumed: applying it here would wait for the loads at
+  //  once and take the prefetch away)
+  f4 sx_sc = (f4)(1.f), sx_sh = (f4)(0.f);
+  unsigned sx_ok = 0;                                         // bit k: piece k is an image pixel (padding must stay zero after the transform)
   auto split_load = [&](int n, int ty0, int tx0) {
+    sx_ok = 0;
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
       const int e = tid + 512 * k;
@@ -81,16 +86,12 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
       const bool ok = px < HWp * HHp && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + i0) * 4 + cqx * 16) : 0xFFFFFFFFu;
       sxr[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-      if (a.in_scale) {                                       // (wave-uniform branch)
-        const f4 sc = *reinterpret_cast<const f4*>(a.in_scale + (long)n * a.Cin + i0 + cqx * 4);
-        const f4 sh = *reinterpret_cast<const f4*>(a.in_shift + (long)n * a.Cin + i0 + cqx * 4);
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          float v = sxr[k][e2] * sc[e2] + sh[e2];
-          if (a.in_relu) v = fmaxf(v, 0.f);
-          sxr[k][e2] = ok ? v : 0.f;
-        }
-      }
+      if (ok) sx_ok |= 1u << k;
+    }
+    if (a.in_scale) {                                         // (wave-uniform branch)  this thread's channel quad is the same for all its pieces
+      const int cqx = tid & (XQ - 1);
+      sx_sc = *reinterpret_cast<const f4*>(a.in_scale + (long)n * a.Cin + i0 + cqx * 4);
+      sx_sh = *reinterpret_cast<const f4*>(a.in_shift + (long)n * a.Cin + i0 + cqx * 4);
     }
 #pragma unroll
     for (int k = 0; k < NDS; ++k) {
@@ -114,7 +115,16 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
     for (int k = 0; k < NXS; ++k) {
       const int e = tid + 512 * k;
       const int px = e / XQ, cqx = e - px * XQ;
-      if (px < HP16 * 16) put(sxr[k], px * 64 + cqx * 8);
+      f4 v = sxr[k];
+      if (a.in_scale) {
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          float t = v[e2] * sx_sc[e2] + sx_sh[e2];
+          if (a.in_relu) t = fmaxf(t, 0.f);
+          v[e2] = ((sx_ok >> k) & 1u) ? t : 0.f;
+        }
+      }
+      if (px < HP16 * 16) put(v, px * 64 + cqx * 8);
     }
 #pragma unroll
     for (int k = 0; k < NDS; ++k) {
