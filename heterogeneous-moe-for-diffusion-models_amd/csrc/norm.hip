@@ -679,8 +679,19 @@ __global__ __launch_bounds__(256) void gn1_relu_mean_kernel(float* out, const fl
   f4 acc = (f4)(0.f);
   if (rw < rows) {
     const f4 sc = *reinterpret_cast<const f4*>(scale + (long)n * C + 4 * cq), sh = *reinterpret_cast<const f4*>(shift + (long)n * C + 4 * cq);
-    for (long s2 = rw; s2 < S; s2 += rows) {
-      const f4 v = *reinterpret_cast<const f4*>(y + ((long)n * S + s2) * C + 4 * cq);
+    const float* yp = y + (long)n * S * C + 4 * cq;
+    long s2 = rw;
+    for (; s2 + 3 * rows < S; s2 += 4 * rows) {                 // four independent 16-byte loads in flight per thread (one block per sample:
+      f4 v[4];                                                  //  the kernel lives on memory-level parallelism, not on occupancy)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f4*>(yp + (s2 + (long)u * rows) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += fmaxf(v[u][e] * sc[e] + sh[e], 0.f);
+    }
+    for (; s2 < S; s2 += rows) {
+      const f4 v = *reinterpret_cast<const f4*>(yp + s2 * C);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += fmaxf(v[e] * sc[e] + sh[e], 0.f);
     }

@@ -187,7 +187,14 @@ class StagedStep:
     def __init__(self, step_fn, device, warmup: int = 3):
         self.device = torch.device(device)
         # the U-Net branch is the longer one (the ViT branch has ~2.5 ms of slack in the backward): its stream gets the higher priority
-        prio = {"main": -1, "u": -1, "v": 0, "r": 0} if __import__("os").environ.get("HDMOE_STREAM_PRIO", "1") != "0" else {"main": 0, "u": 0, "v": 0, "r": 0}
+        # ... but only in a single-process job.  Measured with a one-rank RCCL group (bench.py HDMOE_BENCH_FORCE_DIST=1): as soon as the
+        # process owns one more stream (RCCL's) next to prioritised ones, whole stages run 1.5-2x longer (17.3 -> 22.5 ms/step; a fifth
+        # stream of our own did the same, GPU_MAX_HW_QUEUES=8 did not help); with equal priorities the extra stream costs nothing
+        # (17.3 ms/step including the all-reduces).  So: priorities only when no process group exists.
+        import torch.distributed as dist
+        pmode = __import__("os").environ.get("HDMOE_STREAM_PRIO", "auto")
+        use_prio = pmode == "1" or (pmode == "auto" and not (dist.is_available() and dist.is_initialized()))
+        prio = {"main": -1, "u": -1, "v": 0, "r": 0} if use_prio else {"main": 0, "u": 0, "v": 0, "r": 0}
         self.streams = {k: torch.cuda.Stream(device=self.device, priority=prio[k]) for k in ("main", "u", "v", "r")}
         self.pools = {k: torch.cuda.graph_pool_handle() for k in ("main", "u", "v", "r")}
         cur = torch.cuda.current_stream(self.device)
