@@ -41,9 +41,11 @@ __global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, co
     scale = inv * d.gain * c;
   }
   const bool f32 = d.dtype == HDMOE_F32;
-  for (int e = tid; e < fan; e += blockDim.x) {
-    const int i = e / taps, t = e - i * taps;
-    const float v = w[e] * scale;
+  // image pass in (tap, input channel) order: the forward image [tap][O][Ipad] is written in runs of I consecutive elements (the row
+  // itself, read with stride taps, is 1-25 KB and sits in L1 / L2 after the norm passes); only the flipped image stays scattered
+  for (int e2 = tid; e2 < fan; e2 += blockDim.x) {
+    const int t = e2 / d.I, i = e2 - t * d.I;
+    const float v = w[i * taps + t] * scale;
     const long fi = ((long)t * d.O + o) * d.Ipad + i;
     const long di = ((long)(taps - 1 - t) * d.I + i) * d.Opad + o;
     if (f32) { wb_store<float>((void*)d.wf, fi, v); if (d.wd) wb_store<float>((void*)d.wd, di, v); }
@@ -56,8 +58,11 @@ __global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, co
   }
 }
 
+constexpr int WB_LDS_FLOATS = 2560;          // rows up to this many elements (+ padding) stage their wgrad slab row through LDS (10 KB: 16 blocks per CU stay resident)
+
 __global__ __launch_bounds__(128) void wbank_bwd_kernel(const WBDesc* descs, const int2* rows) {
   __shared__ float sm[16];
+  extern __shared__ float gl[];               // [tap][I + 1]: the row's slice of the [tap][O][I] slab, read coalesced, used in weight order
   const int2 ro = rows[blockIdx.x];
   const WBDesc d = descs[ro.x];
   const int o = ro.y, tid = threadIdx.x;
@@ -65,6 +70,38 @@ __global__ __launch_bounds__(128) void wbank_bwd_kernel(const WBDesc* descs, con
   const float* w = (const float*)d.w_raw + (long)o * fan;
   const float* G = (const float*)d.G;
   float* dw = (float*)d.dw + (long)o * fan;
+  if (taps > 1 && taps * (d.I + 1) <= WB_LDS_FLOATS) {
+    const int Ip = d.I + 1;                   // (+1: consecutive taps of one input channel fall into different banks)
+    for (int e2 = tid; e2 < fan; e2 += blockDim.x) {
+      const int t = e2 / d.I, i = e2 - t * d.I;
+      gl[t * Ip + i] = G[((long)t * d.O + o) * d.I + i];
+    }
+    __syncthreads();
+    if (!d.normalize) {
+      for (int e = tid; e < fan; e += blockDim.x) { const int i = e / taps, t = e - i * taps; dw[e] += d.out_scale * gl[t * Ip + i]; }
+      return;
+    }
+    const float c = rsqrtf((float)fan);
+    float ss = 0.f, gw = 0.f;
+    for (int e = tid; e < fan; e += blockDim.x) {
+      const int i = e / taps, t = e - i * taps;
+      const float v = w[e];
+      ss += v * v;
+      gw += v * gl[t * Ip + i];
+    }
+    ss = block_sum(ss, sm);
+    gw = block_sum(gw, sm);
+    const float n = sqrtf(ss);
+    const float dd = 1e-4f + n * c;
+    const float s = d.gain * c;
+    const float k1 = d.out_scale * s / dd;
+    const float k2 = n > 0.f ? d.out_scale * s * c * gw / (dd * dd * n) : 0.f;
+    for (int e = tid; e < fan; e += blockDim.x) {
+      const int i = e / taps, t = e - i * taps;
+      dw[e] += k1 * gl[t * Ip + i] - k2 * w[e];
+    }
+    return;
+  }
   if (!d.normalize) {
     for (int e = tid; e < fan; e += blockDim.x) {
       const int i = e / taps, t = e - i * taps;
@@ -107,7 +144,7 @@ int hdmoe_wbank_prep(const void* descs, const int* rows, int nrows, int mutate, 
 }
 int hdmoe_wbank_bwd(const void* descs, const int* rows, int nrows, hipStream_t stream) {
   if (nrows < 1) return HDMOE_OK;
-  hipLaunchKernelGGL(wbank_bwd_kernel, dim3(nrows), dim3(128), 0, stream, (const WBDesc*)descs, (const int2*)rows);
+  hipLaunchKernelGGL(wbank_bwd_kernel, dim3(nrows), dim3(128), WB_LDS_FLOATS * sizeof(float), stream, (const WBDesc*)descs, (const int2*)rows);
   return hdmoe_launch_status();
 }
 

@@ -79,6 +79,10 @@ class Stager:
     # therefore gets its own stream and graphs (`ur`, `ur_bwd`), and the combine backward its own small graph (`ucomb_bwd`) so that
     # `ur_bwd` can start right after it, beside the bank backward.
     SPLIT_ROUTER = __import__("os").environ.get("HDMOE_SPLIT_ROUTER", "1") != "0"
+    # The router FORWARD of the U-Net branch is on the critical path (the bank cannot start before the routing weights exist): it runs
+    # on the bank's own (prioritised) stream; only its backward, which has slack, uses the third stream.
+    if __import__("os").environ.get("HDMOE_UR_ON_U", "1") != "0":
+        KIND["ur"] = "u"
 
     def __init__(self, device, streams, pools):
         self.device, self.streams, self.pools = device, streams, pools
@@ -254,10 +258,11 @@ class StagedStep:
             r = S["r"]
             main.wait_stream(cur)
             run("pre", main)
-            r.wait_stream(main); v.wait_stream(main)
-            run("ur", r)
+            ur_s = S[self._keep.KIND["ur"]]
+            ur_s.wait_stream(main); v.wait_stream(main)
+            run("ur", ur_s)
             run("vit", v)
-            u.wait_stream(main); u.wait_stream(r)
+            u.wait_stream(main); u.wait_stream(ur_s)
             run("unet", u)
             main.wait_stream(u); main.wait_stream(v)
             run("post", main)
