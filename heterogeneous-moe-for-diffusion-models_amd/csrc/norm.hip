@@ -671,9 +671,10 @@ __global__ void gn1_finalize_kernel(float* scale, float* shift, float* mean, flo
 }
 // out[n][c] = mean over the S positions of relu(y[n][s][c] * scale[n][c] + shift[n][c]): the last GroupNorm + ReLU + average pool of the
 // trunk in one read of y (fixed summation order)
-__global__ __launch_bounds__(256) void gn1_relu_mean_kernel(float* out, const float* y, const float* scale, const float* shift, long S, int C) {
-  extern __shared__ float part[];                              // [256 / C4][C]
-  const int n = blockIdx.x, C4 = C / 4, rows = 256 / C4;
+constexpr int GN1_POOL_THREADS = 1024;                          // one block per sample: 16 waves keep enough 16-byte loads in flight
+__global__ __launch_bounds__(GN1_POOL_THREADS) void gn1_relu_mean_kernel(float* out, const float* y, const float* scale, const float* shift, long S, int C) {
+  extern __shared__ float part[];                              // [threads / C4][C]
+  const int n = blockIdx.x, C4 = C / 4, rows = GN1_POOL_THREADS / C4;
   const int cq = threadIdx.x % C4, rw = threadIdx.x / C4;
   typedef __attribute__((ext_vector_type(4))) float f4;
   f4 acc = (f4)(0.f);
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256) void gn1_relu_mean_kernel(float* out, const fl
     *reinterpret_cast<f4*>(part + (long)rw * C + 4 * cq) = acc;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += GN1_POOL_THREADS) {
     float t = 0.f;
     for (int k = 0; k < rows; ++k) t += part[(long)k * C + c];
     out[(long)n * C + c] = t / (float)S;
@@ -842,8 +843,8 @@ int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, con
 /* out [N][C] = mean_s relu(y [N][S][C] * scale [N][C] + shift [N][C])   (fp32; C % 4 == 0, C <= 1024) */
 int hdmoe_gn1_relu_mean(float* out, const float* y, const float* scale, const float* shift, int N, long S, int C, hipStream_t stream) {
   if (!out || !y || !scale || !shift || N < 1 || S < 1 || C < 4 || C % 4 || C > 1024) return HDMOE_EINVAL;
-  const int rows = 256 / (C / 4);
-  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(256), (size_t)rows * C * sizeof(float), stream, out, y, scale, shift, S, C);
+  const int rows = GN1_POOL_THREADS / (C / 4);
+  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(GN1_POOL_THREADS), (size_t)rows * C * sizeof(float), stream, out, y, scale, shift, S, C);
   return hdmoe_launch_status();
 }
 
