@@ -10,11 +10,6 @@ latents, per-GPU batch 256, bf16 experts / fp32 stem + router trunks, train() mo
 normalisation all run).  One step = forward + fused EDM_LOSS + backward (+ gradient all-reduce when N > 1), weak scaling.
 Prints ONE JSON line on rank 0.  Only the `cpu_baseline` leg touches oracle/ (the CPU restatement, timed as a baseline).
 """
-import os as _os
-# five streams of our own (four staged-step streams + the default one) and RCCL's: with ROCclr's default of 4 hardware queues per priority
-# level two of them share a queue and whole stages serialise (measured: 17.3 -> 18.0 ms/step; see hdmoe_hip/graph.py).  Must be set before
-# the first HIP call.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import gc
 import json

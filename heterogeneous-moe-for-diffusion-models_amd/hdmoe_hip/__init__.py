@@ -6,14 +6,6 @@
 There is no CPU fallback: importing is cheap, but the first op call loads libhdmoe_hip.so and raises if it is
 missing or the tensors are not on a GPU.
 """
-import os as _os
-
-# The staged step runs four streams of its own next to the default one (and RCCL's in a multi-GPU job).  ROCclr maps streams onto at most
-# GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level; streams that share a queue execute one after the other, and whole
-# stages of the step serialise (measured 17.3 -> 18.0 ms/step).  Read by the HIP runtime at its first call, so this only takes effect
-# when hdmoe_hip is imported before anything touches the GPU -- launchers should export it themselves (bench.py does).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import torch
 
 from . import _lib, ops                                    # noqa: F401

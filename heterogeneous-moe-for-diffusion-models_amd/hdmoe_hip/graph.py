@@ -193,8 +193,12 @@ class StagedStep:
         # the U-Net branch is the longer one (the ViT branch has ~2.5 ms of slack in the backward): its stream gets the higher priority
         # ... but only in a single-process job.  Measured with a one-rank RCCL group (bench.py HDMOE_BENCH_FORCE_DIST=1): as soon as the
         # process owns one more stream (RCCL's) next to prioritised ones, whole stages run 1.5-2x longer (17.3 -> 22.5 ms/step; a fifth
-        # stream of our own did the same, GPU_MAX_HW_QUEUES=8 did not help); with equal priorities the extra stream costs nothing
-        # (17.3 ms/step including the all-reduces).  So: priorities only when no process group exists.
+        # stream of our own did the same); with equal priorities the extra stream costs ~0.2 ms (17.2 vs 17.0 ms/step including the
+        # all-reduces).  So: priorities only when no process group exists.  How ROCclr maps streams onto its hardware queues
+        # (GPU_MAX_HW_QUEUES, default 4 per priority level) decides whether two of our streams end up sharing a queue and whole
+        # stages serialise: measured under the one-rank RCCL group 4 queues 17.2, 8 queues 17.4, 6 queues 20.4 ms/step; without a group
+        # and without priorities 4 queues 18.0, 8 queues 17.6; a ONE-graph replay with an internal fork (the sampler) is 20 % slower
+        # with 8 queues than with 4.  The default (4) is the best setting for every configuration the code itself selects.
         import torch.distributed as dist
         pmode = __import__("os").environ.get("HDMOE_STREAM_PRIO", "auto")
         use_prio = pmode == "1" or (pmode == "auto" and not (dist.is_available() and dist.is_initialized()))
