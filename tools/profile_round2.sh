@@ -25,3 +25,9 @@ cd $R
 cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
 python3 bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/${tag}_conv_events.json > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-600
+# judged copies
+cp gpurun_out/${tag}_stats/s_kernel_stats.csv profiles/${tag}_kernel_stats.csv 2>/dev/null || cp gpurun_out/${tag}_stats/*/s_kernel_stats.csv profiles/${tag}_kernel_stats.csv
+for f in kernel_hist.txt queues.txt pmc_mfma.txt conv_events.json; do cp gpurun_out/${tag}_$f profiles/${tag}_$f; done
+tail -1 gpurun_out/${tag}_bench.json > profiles/${tag}_bench.json
+cp profiles/${tag}_*  gpurun_out/ 2>/dev/null || true
+mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* gpurun_out/profiles_${tag}/
