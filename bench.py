@@ -6,7 +6,8 @@
 
 Workload (BASELINE.json configs[1]): models.model_config1.preconditioned_HDMOEM, reference Utils/configs.py shapes
 (internal_channels 32, R = 32, 4 experts [3x3,3x3,5x5,5x5] / ViT patches [4,8,8,16]) with top_k = 2, synthetic 4x32x32
-latents, per-GPU batch 256, bf16 experts / fp32 stem + router trunks, train() mode (dropout, logit noise, forced weight
+latents, per-GPU batch 256, bf16 experts / fp32 stem + router trunks (the trunks' convs: fp32-equivalent split-bf16 arithmetic in the
+forward -- routing indices bit-exact -- and bf16 operands with fp32 accumulation in the backward), train() mode (dropout, logit noise, forced weight
 normalisation all run).  One step = forward + fused EDM_LOSS + backward (+ gradient all-reduce when N > 1), weak scaling.
 Prints ONE JSON line on rank 0.  Only the `cpu_baseline` leg touches oracle/ (the CPU restatement, timed as a baseline).
 """
@@ -436,7 +437,7 @@ def main():
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if multi else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
+                       "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
             "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "cpu_baseline": cpu,

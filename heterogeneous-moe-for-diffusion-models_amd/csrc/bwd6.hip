@@ -63,13 +63,14 @@ extern "C" {
  * `wd_plane` elements per plane. */
 int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups, long wd_stride,
                      long wd_plane, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw, const int* pt, const int* pl,
-                     float alpha, void* ws, long ws_bytes, const float* in_scale, const float* in_shift, int in_relu, hipStream_t stream) {
+                     float alpha, void* ws, long ws_bytes, const float* in_scale, const float* in_shift, int in_relu, int hi_only, hipStream_t stream) {
   static const bool off = getenv("HDMOE_BWD6") && atoi(getenv("HDMOE_BWD6")) == 0;
   if (off || !dx || !wd || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || Cout % 16) return 1;
   W6DualPlan wp;
   if (wgrad6_plan_split(x, dy, G, seg, ngroups, N, H, W, Cin, Cout, kh, kw, pt, pl, ws, ws_bytes, wp)) return 1;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && (ngroups != 1 || seg))) return HDMOE_EINVAL;
   wp.c[0].in_scale = in_scale; wp.c[0].in_shift = in_shift; wp.c[0].in_relu = in_relu;   // the weight gradient sees relu(x * scale + shift)
+  wp.c[0].hi_only = hi_only ? 1 : 0;
   ConvArgs c;
   c.x = dy; c.w = wd; c.y = dx; c.res = nullptr; c.seg = seg; c.wstride = wd_stride;
   c.N = N; c.H = H; c.W = W; c.Ho = H; c.Wo = W; c.Cin = Cout; c.Cphys = Cout; c.Ipad = Cout; c.Cout = Cin; c.Cstore = Cin;
@@ -77,6 +78,7 @@ int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, fl
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { c.kh[g] = 3; c.kw[g] = 3; c.pt[g] = 1; c.pl[g] = 1; }
   C6SPlan cp;
   if (conv6s_plan(c, wd_plane, nullptr, cp)) return 1;
+  cp.sa.nprod = hi_only ? 1 : 3;
 #define BWD6S_GO(Nt)                                                                             \
   do {                                                                                           \
     if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd6s<Nt, 5, 2>(cp, wp, stream); else launch_bwd6s<Nt, 5, 1>(cp, wp, stream); } \

@@ -70,6 +70,7 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   sa.wplane = (int)(wplane_elems * 2);
   sa.in_scale = fuse ? fuse->in_scale : nullptr; sa.in_shift = fuse ? fuse->in_shift : nullptr; sa.in_relu = fuse ? fuse->in_relu : 0;
   sa.stats = fuse ? fuse->stats : nullptr;
+  sa.nprod = 3;
   const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes + tab_bytes;
   const long tiles = (long)c.N * a.tpi;
   long ub = ((tiles + 1) / 2 + c.ngroups) * a.nblk;

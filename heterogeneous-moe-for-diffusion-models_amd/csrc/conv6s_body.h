@@ -9,6 +9,7 @@ struct C6SArgs {
   int wplane;                         // bytes between the hi and the lo weight image
   const float* in_scale; const float* in_shift; int in_relu;   // fused input transform (or null)
   float* stats;                       // [N][tpi * nblk * 4][2] fp32 partial (sum, sum of squares) of the outputs per sample, or null
+  int nprod;                          // 3: split-bf16 (fp32-equivalent); 1: only x_hi * w_hi = bf16 operands, fp32 accumulation
 };
 struct C6SPlan { C6SArgs sa; int NT; unsigned G; size_t lds; };
 struct ConvFuse;
@@ -152,7 +153,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
       for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
       const int off = pxu * 64 + ((((cq >> 1) ^ ((pxu >> 2) & 3))) << 4) + ((cq & 1) << 3);
       *reinterpret_cast<bf16x4*>(lds + off) = hi;
-      *reinterpret_cast<bf16x4*>(lds + a.hb_bytes + off) = lo;
+      if (sa.nprod == 3) *reinterpret_cast<bf16x4*>(lds + a.hb_bytes + off) = lo;
     }
   };
   // ---- weights (as conv6.hip; plane = 0 hi / 1 lo)
@@ -206,19 +207,20 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
     for (int c = 0; c < nchunks; ++c) {
       const bool last_chunk = c == nchunks - 1;
       const bool more = !last_chunk || has_next;                    // another halo chunk follows (this unit's or the next unit's)
-      for (int prod = 0; prod < 3; ++prod) {                        // x_hi * w_hi, x_hi * w_lo, x_lo * w_hi
+      const int lastp = sa.nprod - 1;                               // nprod = 1: x_hi * w_hi only (plain bf16 operands, the trunk BACKWARD)
+      for (int prod = 0; prod <= lastp; ++prod) {                   // x_hi * w_hi, x_hi * w_lo, x_lo * w_hi
         const int xoff = prod == 2 ? a.hb_bytes : 0;
         int ky = 0, kx = 0;
         for (int tg = 0; tg < cur.ntg; ++tg) {
           const int t0 = tg * a.T;
           const int ntl = min(a.T, cur.ntaps - t0);
-          const bool last_stage = prod == 2 && tg + 1 == cur.ntg;
+          const bool last_stage = prod == lastp && tg + 1 == cur.ntg;
           __syncthreads();
           // ---- next stage's weights
           const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
           int nsb = 0, nwp = 0;
           if (tg + 1 < cur.ntg) { nsb = stage_base(wbase_cur, prod == 1, c, t0 + a.T); nwp = wpieces(min(a.T, cur.ntaps - t0 - a.T)); }
-          else if (prod < 2) { nsb = stage_base(wbase_cur, prod == 0, c, 0); nwp = wpieces(min(a.T, cur.ntaps)); }
+          else if (prod < lastp) { nsb = stage_base(wbase_cur, prod == 0, c, 0); nwp = wpieces(min(a.T, cur.ntaps)); }
           else if (!last_chunk) { nsb = stage_base(wbase_cur, 0, c + 1, 0); nwp = wpieces(min(a.T, cur.ntaps)); }
           else if (has_next) {
             decode(jn, nu);

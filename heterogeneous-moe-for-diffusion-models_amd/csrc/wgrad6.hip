@@ -192,7 +192,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
   const long units_l = (long)N * a.tpi;
   for (int k = 0; k < 2; ++k) {
     const int ks = k == 0 ? 3 : 5;
@@ -231,7 +231,7 @@ int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int*
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
   a.ngr = 0;
   for (int g = 0; g < ngroups; ++g) a.groups[a.ngr++] = g;
   a.pt = 1; a.pl = 1; a.ws_item = 9l * Cout * Cin;
@@ -271,7 +271,7 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
   const long units_l = (long)N * a.tpi;
   bool done[HDMOE_MAX_GROUPS] = {false};
   int cls = 0;

@@ -15,6 +15,7 @@ struct W6Args {
   // SPLIT only: the x operand is relu(x * in_scale[n][c] + in_shift[n][c]) (GroupNorm(1, C) + ReLU of the producing layer applied while
   // the tile is staged -- the normalised activation is never materialised; padding pixels stay zero).  Null = plain x.
   const float* in_scale; const float* in_shift; int in_relu;
+  int hi_only;                        // SPLIT only: 1 = drop the two hi x lo correction products (bf16 operands, fp32 accumulation)
 };
 struct W6DualPlan { W6Args c[2]; int ibs, obs, TWS, OT; size_t lds; };
 // Launch geometry of the deferred dual-class bf16 weight gradient of one layer (wgrad6.hip).  0 = planned, 1 = not applicable.
@@ -109,7 +110,7 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
 #pragma unroll
       for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
       *reinterpret_cast<bf16x4*>(lds + off) = hi;
-      *reinterpret_cast<bf16x4*>(lds + BUF + off) = lo;
+      if (!a.hi_only) *reinterpret_cast<bf16x4*>(lds + BUF + off) = lo;
     };
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
@@ -220,23 +221,34 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
         const int krow = (16 * ks) >> TWS, kcol = (16 * ks) & (TW - 1);
         const int kx_off = (krow * HWp + kcol) * 64;
         const int kdy_off = 16 * ks * DYROW;
-        bf16x8 dh[OT], dl[OT], xh[NFULL + 1], xl[NFULL + 1];
+        bf16x8 dh[OT], xh[NFULL + 1];
 #pragma unroll
-        for (int t = 0; t < OT; ++t) { dh[t] = tr2(XBUF + dylane[t] + kdy_off, 4 * DYROW); dl[t] = tr2(BUF + XBUF + dylane[t] + kdy_off, 4 * DYROW); }
+        for (int t = 0; t < OT; ++t) dh[t] = tr2(XBUF + dylane[t] + kdy_off, 4 * DYROW);
 #pragma unroll
-        for (int s2 = 0; s2 <= NFULL; ++s2) { xh[s2] = tr2(xlane + tapoff[s2] + kx_off, 4 * 64); xl[s2] = tr2(BUF + xlane + tapoff[s2] + kx_off, 4 * 64); }
+        for (int s2 = 0; s2 <= NFULL; ++s2) xh[s2] = tr2(xlane + tapoff[s2] + kx_off, 4 * 64);
 #pragma unroll
         for (int s2 = 0; s2 < NFULL; ++s2)
 #pragma unroll
-          for (int t = 0; t < OT; ++t) {
-            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xh[s2], acc[s2][t], 0, 0, 0);
-            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xl[s2], acc[s2][t], 0, 0, 0);
-            acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[t], xh[s2], acc[s2][t], 0, 0, 0);
-          }
-        const bf16x8 deh = (OT == 2 && eob) ? dh[OT - 1] : dh[0], del = (OT == 2 && eob) ? dl[OT - 1] : dl[0];
+          for (int t = 0; t < OT; ++t) acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xh[s2], acc[s2][t], 0, 0, 0);
+        const bf16x8 deh = (OT == 2 && eob) ? dh[OT - 1] : dh[0];
         acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(deh, xh[NFULL], acce, 0, 0, 0);
-        acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(deh, xl[NFULL], acce, 0, 0, 0);
-        acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(del, xh[NFULL], acce, 0, 0, 0);
+        if (!a.hi_only) {                                       // (wave-uniform) the two correction products: dy_hi * x_lo + dy_lo * x_hi
+          bf16x8 dl[OT], xl[NFULL + 1];
+#pragma unroll
+          for (int t = 0; t < OT; ++t) dl[t] = tr2(BUF + XBUF + dylane[t] + kdy_off, 4 * DYROW);
+#pragma unroll
+          for (int s2 = 0; s2 <= NFULL; ++s2) xl[s2] = tr2(BUF + xlane + tapoff[s2] + kx_off, 4 * 64);
+#pragma unroll
+          for (int s2 = 0; s2 < NFULL; ++s2)
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+              acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[t], xl[s2], acc[s2][t], 0, 0, 0);
+              acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[t], xh[s2], acc[s2][t], 0, 0, 0);
+            }
+          const bf16x8 del = (OT == 2 && eob) ? dl[OT - 1] : dl[0];
+          acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(deh, xl[NFULL], acce, 0, 0, 0);
+          acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(del, xh[NFULL], acce, 0, 0, 0);
+        }
       }
       if (more) {
         __syncthreads();                                      // every wave is done reading tile u

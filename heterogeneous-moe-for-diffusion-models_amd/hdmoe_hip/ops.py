@@ -448,7 +448,7 @@ class _MPConvFn(torch.autograd.Function):
                 Opad = (O + 15) // 16 * 16
                 wdstride = 9 * I * Opad
                 if call("hdmoe_conv_bwd6s", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, G * wdstride, N, H, W, I, O, khs, kws, pts, pts,
-                        alpha, ws, ws.numel() * 4, None, None, 0) == 0:
+                        alpha, ws, ws.numel() * 4, None, None, 0, 1 if TRUNK_BWD_BF16 else 0) == 0:
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, F32S, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
@@ -1566,6 +1566,10 @@ def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, act: int = A
 
 
 TRUNK_FUSED = _os.environ.get("HDMOE_TRUNK_FUSED", "1") != "0"
+# bf16 compute mode only (the split kernels): the router trunks' BACKWARD (input + weight gradients of their convs) uses the hi halves of
+# the split operands only -- bf16 operands, fp32 accumulation, one MFMA per product instead of three.  Bit-exact routing indices need
+# the fp32-equivalent FORWARD (three products); gradients carry the bf16 mode's tolerance like every expert layer.  0: three products.
+TRUNK_BWD_BF16 = _os.environ.get("HDMOE_TRUNK_BWD_BF16", "1") != "0"
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -1640,7 +1644,7 @@ class _TrunkFn(torch.autograd.Function):
             da = torch.empty_like(xin)
             wdstride = 9 * I * ((O + 15) // 16 * 16)
             if call("hdmoe_conv_bwd6s", xin, dy, ent.wd, da, list(ent.G), None, 1, wdstride, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
-                    arena, arena.numel() * 4, isc, ish, 1) != 0:
+                    arena, arena.numel() * 4, isc, ish, 1, 1 if TRUNK_BWD_BF16 else 0) != 0:
                 raise RuntimeError("router trunk backward: layer outside the fused backward kernel's domain")
             bank.defer_w6(list(ent.G), None, arena, [1, N, H, W, I, O, F32S, 0, 3, 0, 0, 0, 0, 0, 0, 0])
             bank.note_backward(ent)

@@ -85,7 +85,8 @@ int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, flo
 int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, float* const* G, const int* seg, int ngroups,
                      long wd_stride, long wd_plane, int N, int H, int W, int Cin, int Cout, const int* kh, const int* kw,
                      const int* pt, const int* pl, float alpha, void* ws, long ws_bytes, const float* in_scale, const float* in_shift,
-                     int in_relu, HS stream);   /* fp32 tensors, split bf16 (3x3); in_scale / in_shift (or NULL): x is relu(x * scale[n][c] + shift[n][c]) */
+                     int in_relu, int hi_only, HS stream);   /* fp32 tensors, split bf16 (3x3); in_scale / in_shift (or NULL): x is relu(x * scale[n][c] + shift[n][c]);
+                                                 hi_only = 1: bf16 operands (the hi halves) with fp32 accumulation -- one MFMA per product instead of three */
 /* GroupNorm(1, C) + ReLU of the router trunks fused into the neighbouring convs (model_components.py:100-112): the conv writes per-sample
  * partial statistics of its output, hdmoe_gn1_finalize turns them into mean / rstd and a per-(sample, channel) scale / shift, the NEXT
  * conv (and its weight gradient, hdmoe_conv_bwd6s) apply relu(x * scale + shift) while staging x, hdmoe_gn1_relu_mean is the last

@@ -1165,12 +1165,16 @@ def test_multi_linear_matches_the_per_layer_path(G, R, I, Os, four_d):
         close_scaled(a, b, 5e-6, msg=f"dw[{k}]", atol=1e-6 * gmax)
 
 
+@pytest.mark.parametrize("bwd_bf16", [False, True])
 @pytest.mark.parametrize("N,H,C,k", [(5, 32, 32, 2), (3, 16, 32, 1), (9, 64, 32, 1)])
-def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k):
+def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k, bwd_bf16):
     """Router.hard_route with GroupNorm(1, C) + ReLU folded into the neighbouring split-bf16 convs (ops.router_trunk: statistics from the
     conv epilogue, the affine + ReLU applied while the next conv / weight gradient stage the tensor, pooled read at the end) against the
     layer-by-layer path (conv, GroupNorm kernel, seq_mean -- pinned to the reference by the router golden vectors): logits, top-k
-    indices (bit-exact), input and parameter gradients; and a sample's logits must not depend on its batch."""
+    indices (bit-exact), input and parameter gradients; and a sample's logits must not depend on its batch.
+    bwd_bf16: the trunk backward with bf16 operands (ops.TRUNK_BWD_BF16, the bf16 mode's default) -- the two paths then round
+    slightly different fp32 activations to bf16, so their gradients agree at the bf16 level only; with the three-product backward
+    they agree at the fp32 level."""
     import hdmoe_hip
     import models.model_components as mc
     from hdmoe_hip import ops, bank as wbank
@@ -1183,7 +1187,10 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k):
     x = torch.randn(N, C, H, H, device=DEV)
     te = torch.randn(N, 16, device=DEV)
     prev = hdmoe_hip.compute_dtype()
+    prev_bwd = ops.TRUNK_BWD_BF16
     hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    ops.TRUNK_BWD_BF16 = bwd_bf16
+    grel = 2e-2 if bwd_bf16 else 2e-4
     res = {}
     try:
         for mode in ("warm", "layers", "fused", "fused_sub"):
@@ -1199,6 +1206,7 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k):
             r.zero_grad(set_to_none=False)
     finally:
         ops.TRUNK_FUSED = True
+        ops.TRUNK_BWD_BF16 = prev_bwd
         hdmoe_hip.set_compute_dtype(prev)
     assert all(e.ready for e in r._hdmoe_bank.entries.values())
     (l0, dx0, pg0), (l1, dx1, pg1), (l2, _, _) = res["layers"], res["fused"], res["fused_sub"]
@@ -1207,12 +1215,12 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k):
     assert torch.equal(l2, l1[1:3])                                # statistics are summed per sample in a fixed order
     # (the two paths round scale / shift differently: an activation within ~1e-7 of zero may land on the other side of the ReLU, which
     #  moves the few input-gradient elements under that pixel's 3x3 footprints by a per cent or so)
-    close_scaled(dx1, dx0, 2e-4, msg="dx", outlier_frac=1e-3)
+    close_scaled(dx1, dx0, grel, msg="dx", outlier_frac=1e-3)
     close_scaled(dx1, dx0, 1e-1, msg="dx (all)")
     assert set(pg0) == set(pg1)
     for n in pg0:
         # (H = 64: 4.7M activations per layer, a ReLU flip or two is expected -- one flipped pixel of 37k moves a weight gradient ~1e-3)
-        close_scaled(pg1[n], pg0[n], 2e-4 if H < 64 else 1e-2, msg=n, atol=2e-6 * float(pg0[n].abs().max()) + 1e-9)
+        close_scaled(pg1[n], pg0[n], max(grel, 2e-4 if H < 64 else 1e-2), msg=n, atol=2e-6 * float(pg0[n].abs().max()) + 1e-9)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1355,16 +1363,20 @@ def test_staged_step_matches_plain_backward():
         del junk
 
 
-def test_full_size_batch_independence_and_router_invariants():
+@pytest.mark.parametrize("trunk_bwd_bf16", [False, True])
+def test_full_size_batch_independence_and_router_invariants(trunk_bwd_bf16):
     """BASELINE config 2 at its FULL size (B = 256, bf16 experts, 4x32x32 latents, text 77x768), through properties that do not
     need the oracle at that size: routing is per sample, so a sample's output (bit for bit) and input-gradient must not depend
     on which other samples share its batch (full batch == two half batches, which exercise different expert-row groupings,
     tile counts and flattened-row lengths); every router row has exactly k non-zero weights that sum to 1, zero weight on masked experts; nothing is NaN."""
     import hdmoe_hip
+    from hdmoe_hip import ops
     from Utils import configs
     from models import model_config1
     from oracle.recipe import fill_state
     hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    prev_bwd = ops.TRUNK_BWD_BF16
+    ops.TRUNK_BWD_BF16 = trunk_bwd_bf16
     try:
         kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
         model = model_config1.preconditioned_HDMOEM(**kw)
@@ -1394,7 +1406,10 @@ def test_full_size_batch_independence_and_router_invariants():
             b = torch.cat([h1[key].detach().float(), h2[key].detach().float()])
             assert torch.isfinite(a[torch.isfinite(b)]).all(), key
             assert torch.equal(a, b), key                           # forward is atomic-free: bit-identical per sample
-        close_scaled(gfull, torch.cat([g1, g2]), 1e-5, msg="x.grad")    # backward sums a few terms with float atomics
+        # backward sums a few terms with float atomics (1e-7 run-to-run): 1e-5 with the three-product trunk backward.  With bf16 operands
+        # in the trunk backward (ops.TRUNK_BWD_BF16, the default of this mode) such a perturbation becomes a one-ulp bf16 change
+        # (4e-3 relative) of the odd operand element: measured 1e-5 ... 7e-5 of the tensor's maximum from run to run
+        close_scaled(gfull, torch.cat([g1, g2]), 3e-4 if trunk_bwd_bf16 else 1e-5, msg="x.grad")
         for key, mask in (("Unet_raw", um), ("vit_raw", vm)):
             logits = full[key].detach().float()
             assert bool(((logits == float("-inf")) == (mask == 0)).all()), key          # masked experts: -inf logits
@@ -1403,4 +1418,5 @@ def test_full_size_batch_independence_and_router_invariants():
         probs = full["Unet_router_loss"].detach().float()
         assert torch.allclose(probs.sum(-1), torch.ones(B, device=DEV), atol=1e-5) and bool((probs[um == 0] == 0).all())
     finally:
+        ops.TRUNK_BWD_BF16 = prev_bwd
         hdmoe_hip.set_compute_dtype(torch.float32)
