@@ -672,14 +672,50 @@ __global__ void gn1_finalize_kernel(float* scale, float* shift, float* mean, flo
 // out[n][c] = mean over the S positions of relu(y[n][s][c] * scale[n][c] + shift[n][c]): the last GroupNorm + ReLU + average pool of the
 // trunk in one read of y (fixed summation order)
 constexpr int GN1_POOL_THREADS = 1024;                          // one block per sample: 16 waves keep enough 16-byte loads in flight
-__global__ __launch_bounds__(GN1_POOL_THREADS) void gn1_relu_mean_kernel(float* out, const float* y, const float* scale, const float* shift, long S, int C) {
+// ws != null: the statistics of y come as the producing conv's partial slots (the gn1_finalize step folded in: a launch less in the
+// router's serial chain -- where a tiny kernel queues behind the other branch's persistent conv); scale / shift / mean / rstd are
+// then OUTPUTS (kept for the backward).
+__global__ __launch_bounds__(GN1_POOL_THREADS) void gn1_relu_mean_kernel(float* out, const float* y, float* scale, float* shift, long S, int C,
+                                                                       const float* ws, const float* gamma, const float* beta, float* mean,
+                                                                       float* rstd, int slots, float inv_count, float eps) {
   extern __shared__ float part[];                              // [threads / C4][C]
+  __shared__ float smr[2];
   const int n = blockIdx.x, C4 = C / 4, rows = GN1_POOL_THREADS / C4;
   const int cq = threadIdx.x % C4, rw = threadIdx.x / C4;
   typedef __attribute__((ext_vector_type(4))) float f4;
+  if (ws) {                                                    // same arithmetic and order as gn1_finalize_kernel
+    double s1 = 0.0, s2 = 0.0;
+    if (threadIdx.x < 64) {
+      for (int k = threadIdx.x; k < slots; k += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(ws + ((long)n * slots + k) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_down(s1, d, 64); s2 += __shfl_down(s2, d, 64); }
+    }
+    if (threadIdx.x == 0) {
+      const double m = s1 * inv_count;
+      double var = s2 * inv_count - m * m;
+      if (var < 0.0) var = 0.0;
+      smr[0] = (float)m; smr[1] = (float)(1.0 / sqrt(var + (double)eps));
+      mean[n] = smr[0]; rstd[n] = smr[1];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GN1_POOL_THREADS) {
+      const float g = gamma[c] * smr[1];
+      scale[(long)n * C + c] = g;
+      shift[(long)n * C + c] = beta[c] - smr[0] * g;
+    }
+  }
   f4 acc = (f4)(0.f);
   if (rw < rows) {
-    const f4 sc = *reinterpret_cast<const f4*>(scale + (long)n * C + 4 * cq), sh = *reinterpret_cast<const f4*>(shift + (long)n * C + 4 * cq);
+    f4 sc, sh;
+    if (ws) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float g = gamma[4 * cq + e] * smr[1]; sc[e] = g; sh[e] = beta[4 * cq + e] - smr[0] * g; }
+    } else {
+      sc = *reinterpret_cast<const f4*>(scale + (long)n * C + 4 * cq); sh = *reinterpret_cast<const f4*>(shift + (long)n * C + 4 * cq);
+    }
     const float* yp = y + (long)n * S * C + 4 * cq;
     long s2 = rw;
     for (; s2 + 3 * rows < S; s2 += 4 * rows) {                 // four independent 16-byte loads in flight per thread (one block per sample:
@@ -844,7 +880,19 @@ int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, con
 int hdmoe_gn1_relu_mean(float* out, const float* y, const float* scale, const float* shift, int N, long S, int C, hipStream_t stream) {
   if (!out || !y || !scale || !shift || N < 1 || S < 1 || C < 4 || C % 4 || C > 1024) return HDMOE_EINVAL;
   const int rows = GN1_POOL_THREADS / (C / 4);
-  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(GN1_POOL_THREADS), (size_t)rows * C * sizeof(float), stream, out, y, scale, shift, S, C);
+  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(GN1_POOL_THREADS), (size_t)rows * C * sizeof(float), stream, out, y, (float*)scale, (float*)shift,
+                     S, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0.f, 0.f);
+  return hdmoe_launch_status();
+}
+/* hdmoe_gn1_finalize + hdmoe_gn1_relu_mean in one launch: statistics from the conv's partial slots ws [N][slots][2]; scale / shift [N][C] and
+ * mean / rstd [N] are written (for the backward), out [N][C] = mean_s relu(GroupNorm(1, C)(y)). */
+int hdmoe_gn1_finalize_relu_mean(float* out, float* scale, float* shift, float* mean, float* rstd, const float* y, const float* ws,
+                                 const float* gamma, const float* beta, int N, int slots, long S, int C, float eps, hipStream_t stream) {
+  if (!out || !y || !scale || !shift || !mean || !rstd || !ws || !gamma || !beta || N < 1 || slots < 1 || S < 1 || C < 4 || C % 4 || C > 1024)
+    return HDMOE_EINVAL;
+  const int rows = GN1_POOL_THREADS / (C / 4);
+  hipLaunchKernelGGL(gn1_relu_mean_kernel, dim3(N), dim3(GN1_POOL_THREADS), (size_t)rows * C * sizeof(float), stream, out, y, scale, shift, S, C, ws,
+                     gamma, beta, mean, rstd, slots, 1.f / ((float)S * (float)C), eps);
   return hdmoe_launch_status();
 }
 

@@ -1602,11 +1602,15 @@ class _TrunkFn(torch.autograd.Function):
             sh = torch.empty_like(sc)
             mean = torch.empty(N, dtype=torch.float32, device=x.device)
             rstd = torch.empty_like(mean)
-            call("hdmoe_gn1_finalize", sc, sh, mean, rstd, ws, gamma, beta, N, slots, O, S * O, eps[l])
+            if l < 2:
+                # (folding this step into the consuming conv as well -- every workgroup re-deriving mean / rstd from the slots in fp64 --
+                #  was measured 0.08 ms/step SLOWER: register spills in the 128-channel kernel; tried and removed)
+                call("hdmoe_gn1_finalize", sc, sh, mean, rstd, ws, gamma, beta, N, slots, O, S * O, eps[l])
+            else:                                               # last layer: statistics -> scale / shift inside the pooled read's launch
+                out = torch.empty((N, O), dtype=torch.float32, device=x.device)
+                call("hdmoe_gn1_finalize_relu_mean", out, sc, sh, mean, rstd, y, ws, gamma, beta, N, slots, S, O, eps[l])
             saved += [y, sc, sh, mean, rstd]
             inp = y
-        out = torch.empty((N, O), dtype=torch.float32, device=x.device)
-        call("hdmoe_gn1_relu_mean", out, inp, sc, sh, N, S, O)
         ctx.save_for_backward(x, *saved, *tensors)
         ctx.ents, ctx.bank = ents, bank
         return out

@@ -97,6 +97,8 @@ int hdmoe_conv_split_stats_slots(int H, int W, int Cout);   /* partial-statistic
 int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, const float* ws, const float* gamma, const float* beta,
                        int N, int slots, int C, long count, float eps, HS stream);
 int hdmoe_gn1_relu_mean(float* out, const float* y, const float* scale, const float* shift, int N, long S, int C, HS stream);
+int hdmoe_gn1_finalize_relu_mean(float* out, float* scale, float* shift, float* mean, float* rstd, const float* y, const float* ws,
+                                 const float* gamma, const float* beta, int N, int slots, long S, int C, float eps, HS stream);   /* the two above in one launch */
 int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float* const* ws, const int* dims, int n, HS stream);
 
 /* development hook of the conv6 kernels: `buf` = device array of 8 x 64 uint64 receiving workgroup 0's in-kernel clock stamps
