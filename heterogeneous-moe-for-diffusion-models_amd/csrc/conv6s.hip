@@ -74,7 +74,11 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes + tab_bytes;
   const long tiles = (long)c.N * a.tpi;
   long ub = ((tiles + 1) / 2 + c.ngroups) * a.nblk;
-  plan.G = (unsigned)(ub < 256 ? ub : 256);
+  // 224, not 256, persistent workgroups: one of these takes a CU's whole register file, so on a full grid NOTHING of the other branches
+  // can start until it ends; leaving 32 CUs free lets their small kernels through (16.17 -> 16.00 ms/step, three same-box pairs;
+  // 192 / 208: 16.04 / 16.08, 128: 16.27)
+  static const long gcap = getenv("HDMOE_C6S_G") ? atol(getenv("HDMOE_C6S_G")) : 224;
+  plan.G = (unsigned)(ub < gcap ? ub : gcap);
   plan.NT = NT; plan.lds = lds;
   return 0;
 }
