@@ -131,3 +131,27 @@ static inline int hdmoe_launch_status() {
   return hipGetLastError() == hipSuccess ? HDMOE_OK : HDMOE_ELAUNCH;
 }
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- counter RNG (Philox4x32-10)
+DEVI void philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
+  uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+}
+DEVI float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.f / 16777216.f); }
+
+// the Philox key is (per-call salt) + (device step counter) * golden ratio: a captured hipGraph replays with fresh randomness
+// because the counter lives in device memory and is advanced by hdmoe_seed_advance once per step
+DEVI void mix_seed(uint32_t& lo, uint32_t& hi, const unsigned long long* seed_dev) {
+  if (seed_dev) {
+    const unsigned long long k = (((unsigned long long)hi << 32) | lo) + (*seed_dev) * 0x9E3779B97F4A7C15ull;
+    lo = (uint32_t)k; hi = (uint32_t)(k >> 32);
+  }
+}

@@ -1483,6 +1483,30 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
 }
 
 
+/* Grouped k x k bf16 conv (the conv6 domain: stride 1, "same" padding, square k in {3,5,7}, Cin % 32 == Cout % 32 == 0) with the FiLM of
+ * Unet_block fused into its epilogue (reference model_components.py:242-246): y = alpha * conv(x, w) as hdmoe_conv_fwd, and
+ * h = dropout_p(mp_silu(y * e[n][c])) -- bit for bit what hdmoe_film_silu_drop_fwd(h, y, e, ..., seed, seed_dev, p) writes.
+ * Returns 1 without launching when the layer is outside the domain (the caller then issues the two launches). */
+int hdmoe_conv_fwd_film(const void* x, const void* w, void* y, void* h, const float* e, unsigned long long seed,
+                        const unsigned long long* seed_dev, float p, float alpha, const int* seg, int ngroups, long wstride, int N, int H, int W,
+                        int Cin, int Cout, const int* kh, const int* kw, const int* pt, const int* pl, int dtype, hipStream_t stream) {
+  if (!x || !w || !y || !h || !e || N < 0 || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS || p < 0.f || p >= 1.f) return HDMOE_EINVAL;
+  if (dtype != HDMOE_BF16) return 1;
+  if (N == 0) return HDMOE_OK;
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.res = nullptr; a.seg = seg; a.wstride = wstride;
+  a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cin = Cin; a.Cphys = Cin; a.Ipad = Cin; a.Cout = Cout; a.Cstore = Cout;
+  a.stride = 1; a.ones = 0; a.ngroups = ngroups; a.alpha = alpha; a.beta = 0.f; a.n0 = 0;
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
+    const int s = g < ngroups ? g : 0;
+    a.kh[g] = kh[s]; a.kw[g] = kw[s]; a.pt[g] = pt[s]; a.pl[g] = pl[s];
+  }
+  ConvFuse f;
+  f.in_scale = nullptr; f.in_shift = nullptr; f.stats = nullptr; f.in_relu = 0;
+  f.film_e = e; f.film_h = h; f.film_seed_dev = seed_dev; f.film_seed = seed; f.film_p = p;
+  return conv6_try_launch(a, &f, dtype, stream);
+}
+
 /* 3x3 "same" conv of an fp32 tensor as split bf16 (conv6s) with GroupNorm(1, C) + ReLU of the PRODUCING layer applied to x while it is
  * staged (in_scale / in_shift [N][Cin] from hdmoe_gn1_finalize, or NULL) and per-sample partial statistics of y written to stats_ws
  * ([N][hdmoe_conv_split_stats_slots][2] floats, or NULL).  w: [hi | lo] bf16 image, wplane elements per plane.  Returns 1 when the shape

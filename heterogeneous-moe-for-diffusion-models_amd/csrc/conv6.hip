@@ -22,9 +22,9 @@
 
 namespace {
 
-template <int MT, int NT>
+template <int MT, int NT, bool FILM = false>
 __global__ __launch_bounds__(64 * C6_NW) void conv6_bf16_kernel(C6Args a) {
-  conv6_body<MT, NT>(a, blockIdx.x, gridDim.x);
+  conv6_body<MT, NT, FILM>(a, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -58,6 +58,7 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
   static const int dbg = getenv("HDMOE_C6_DBG") ? atoi(getenv("HDMOE_C6_DBG")) : 0;
   a.dbg = dbg;
   a.stamps = (unsigned long long*)g_c6_stamps;
+  a.film_e = nullptr; a.film_h = nullptr; a.film_seed_dev = nullptr; a.film_seed_lo = 0; a.film_seed_hi = 0; a.film_p = 0.f;
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.ks[g] = c.kh[g]; a.pt[g] = c.pt[g]; a.pl[g] = c.pl[g]; a.order[g] = g; }
   for (int i = 1; i < c.ngroups; ++i)                       // groups by descending kernel size (longest units first)
     for (int k = i; k > 0 && a.ks[a.order[k]] > a.ks[a.order[k - 1]]; --k) { const int t = a.order[k]; a.order[k] = a.order[k - 1]; a.order[k - 1] = t; }
@@ -107,9 +108,14 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
 }
 
 int conv6_try_launch(const ConvArgs& c, const ConvFuse* fuse, int dtype, hipStream_t stream) {
-  if (fuse) return 1;
+  if (fuse && (fuse->in_scale || fuse->in_shift || fuse->stats)) return 1;
   C6Plan plan;
   if (conv6_plan(c, dtype, plan)) return 1;
+  if (fuse && fuse->film_e) {                                // FiLM epilogue: second output tensor
+    if (!fuse->film_h || (((uintptr_t)fuse->film_h) & 15) || c.res) return 1;
+    plan.a.film_e = fuse->film_e; plan.a.film_h = fuse->film_h; plan.a.film_seed_dev = fuse->film_seed_dev;
+    plan.a.film_seed_lo = (unsigned)fuse->film_seed; plan.a.film_seed_hi = (unsigned)(fuse->film_seed >> 32); plan.a.film_p = fuse->film_p;
+  }
   const C6Args& a = plan.a;
   const unsigned G = plan.G;
   const size_t lds = plan.lds;
@@ -119,6 +125,14 @@ int conv6_try_launch(const ConvArgs& c, const ConvFuse* fuse, int dtype, hipStre
     attr_set = true;
 #define C6_ATTR(M, Nt) (void)hipFuncSetAttribute((const void*)conv6_bf16_kernel<M, Nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     C6_ATTR(1, 1); C6_ATTR(1, 2); C6_ATTR(2, 1); C6_ATTR(2, 2);
+#define C6F_ATTR(M, Nt) (void)hipFuncSetAttribute((const void*)conv6_bf16_kernel<M, Nt, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    C6F_ATTR(1, 1); C6F_ATTR(1, 2); C6F_ATTR(2, 1); C6F_ATTR(2, 2);
+  }
+  if (a.film_e) {
+#define C6F_LAUNCH(M, Nt) hipLaunchKernelGGL((conv6_bf16_kernel<M, Nt, true>), dim3(G), dim3(64 * C6_NW), lds, stream, a)
+    if (MT == 2) { if (NT == 2) C6F_LAUNCH(2, 2); else C6F_LAUNCH(2, 1); }
+    else { if (NT == 2) C6F_LAUNCH(1, 2); else C6F_LAUNCH(1, 1); }
+    return hdmoe_launch_status();
   }
 #define C6_LAUNCH(M, Nt) hipLaunchKernelGGL((conv6_bf16_kernel<M, Nt>), dim3(G), dim3(64 * C6_NW), lds, stream, a)
   if (MT == 2) { if (NT == 2) C6_LAUNCH(2, 2); else C6_LAUNCH(2, 1); }

@@ -6,7 +6,7 @@
 
 namespace {
 
-template <int MT, int NT>
+template <int MT, int NT, bool FILM = false>
 DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
 #if __HIP_DEVICE_COMPILE__                     // (the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub)
   constexpr int NB = 32 * NT;
@@ -27,6 +27,9 @@ DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
 
+  uint32_t film_lo = a.film_seed_lo, film_hi = a.film_seed_hi;
+  if (FILM && a.film_e && a.film_p > 0.f) mix_seed(film_lo, film_hi, a.film_seed_dev);
+  const float film_inv = a.film_p > 0.f ? 1.f / (1.f - a.film_p) : 1.f;
   int nstamp = 0;
   auto stamp = [&](int tag) {
     if (a.stamps && bid == 0 && lane == 0 && nstamp < 63) {
@@ -339,6 +342,31 @@ DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
             const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
             const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
             if (ok) *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (FILM && a.film_e && ok) {
+              // FiLM + mp_silu + dropout of the 8 channels this lane just stored (from the bf16-ROUNDED values, as the separate pass reads them)
+              const long eo = pix + 32 * b + 16 * p + 8 * h;                  // element index of the first of the 8 channels
+              const int c0 = cur.nbk * NB + 32 * b + 16 * p + 8 * h;
+              const unsigned pk[4] = {s0[0], s1[0], s0[1], s1[1]};
+              uint32_t r4[8];
+              if (a.film_p > 0.f) {
+                const long q0 = eo >> 2;
+                philox((uint32_t)q0, (uint32_t)(q0 >> 32), film_lo, film_hi, r4);
+                philox((uint32_t)(q0 + 1), (uint32_t)((q0 + 1) >> 32), film_lo, film_hi, r4 + 4);
+              }
+              unsigned ho[4];
+#pragma unroll
+              for (int j2 = 0; j2 < 4; ++j2) {
+                const bf2 yv = __builtin_bit_cast(bf2, pk[j2]);
+                float f0 = mp_silu_f((float)yv[0] * a.film_e[(long)n * a.Cout + c0 + 2 * j2]);
+                float f1 = mp_silu_f((float)yv[1] * a.film_e[(long)n * a.Cout + c0 + 2 * j2 + 1]);
+                if (a.film_p > 0.f) {
+                  f0 = u01(r4[2 * j2]) >= a.film_p ? f0 * film_inv : 0.f;
+                  f1 = u01(r4[2 * j2 + 1]) >= a.film_p ? f1 * film_inv : 0.f;
+                }
+                ho[j2] = __builtin_bit_cast(unsigned, (bf2){(bf16)f0, (bf16)f1});
+              }
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(a.film_h) + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+            }
           }
       }
     }

@@ -20,6 +20,10 @@ struct C6Args {
   unsigned m_nblk, m_T, m_tpi, m_tx;  // 2^32 / d + 1 reciprocals of nblk, T, tpi, tiles_x
   int dbg;                            // development ablations: 1 skip the MFMA loop, 2 skip the in-loop DMA, 4 skip the stores
   unsigned long long* stamps;         // development: s_memtime stamps of workgroup 0 ([wave][64] slots), or null
+  // fused FiLM epilogue (Unet_block, reference model_components.py:242-246): besides y the kernel writes
+  // film_h = dropout_p(mp_silu(y * film_e[n][c])) -- the same arithmetic and the same Philox bits as film_silu_fwd_vec_kernel
+  // (elementwise.hip) on the bf16-rounded y, so the separate pass (and its launch on the U-Net branch's serial chain) disappears.
+  const float* film_e; void* film_h; const unsigned long long* film_seed_dev; unsigned film_seed_lo, film_seed_hi; float film_p;
 };
 
 template <int MT>

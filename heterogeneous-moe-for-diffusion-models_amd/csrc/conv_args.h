@@ -20,11 +20,14 @@ struct ConvArgs {
 //   in_scale/in_shift [N][Cin] fp32 + in_relu: the staged input is relu(x * scale[n][c] + shift[n][c]) -- GroupNorm(1,C) + ReLU of the
 //   producing layer folded into this layer's staging pass (Router.hard_route, reference model_components.py:100-112);
 //   stats [N][2] fp32 (caller zeroes): per-sample sum and sum of squares of the fp32 outputs, accumulated for the NEXT GroupNorm.
+//   film_e != null (bf16 conv6 only): second output film_h = dropout_p(mp_silu(y * film_e[n][c])) (FiLM of Unet_block, conv6_common.h).
 struct ConvFuse {
   const float* in_scale;
   const float* in_shift;
   float* stats;
   int in_relu;
+  const float* film_e = nullptr; void* film_h = nullptr; const unsigned long long* film_seed_dev = nullptr;
+  unsigned long long film_seed = 0; float film_p = 0.f;
 };
 
 // Returns HDMOE_OK after launching, a negative status on a launch error, or 1 when the shape is outside conv6's domain

@@ -396,8 +396,19 @@ class _MPConvFn(torch.autograd.Function):
         ctx.ent = ent
         ctx.bank = _bank.ACTIVE if ent is not None else None
         y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
-        _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys, split), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
-               seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, dtc)
+        req = _FILM_REQ
+        fused_film = False
+        if (req is not None and ent is not None and not split and res is None and not ones and x.dtype == torch.bfloat16 and PROFILE is None
+                and Ho == H and Wo == W and Cphys == I):
+            # FiLM + mp_silu + dropout as a second output of this conv's epilogue (ops.mp_conv_film): one launch less on the branch's chain
+            hbuf = torch.empty_like(y)
+            if call("hdmoe_conv_fwd_film", x, wf, y, hbuf, req.emb, req.seed, step_counter(x.device), req.p, alpha, seg, G, wstride, N, H, W, I, O,
+                    khs, kws, pts, pts, dtc) == 0:
+                req.h = hbuf
+                fused_film = True
+        if not fused_film:
+            _timed("conv_fwd", _conv_info(x, seg, N, Ho, Wo, O, I, O, khs, kws, Cphys, split), "hdmoe_conv_fwd", x, wf, y, _c(res), alpha, beta,
+                   seg, G, wstride, N, H, W, Ho, Wo, I, Cphys, Ipad, O, O, 1, 1 if ones else 0, khs, kws, pts, pts, dtc)
         ctx.save_for_backward(x, seg, *tensors)
         ctx.meta = (G, gain_val, alpha, beta, ones, normalize, khs, kws, pts, Ho, Wo, res is not None, split, res_raw)
         return y
@@ -903,6 +914,56 @@ class _FilmSiluFn(torch.autograd.Function):
         else:
             call("hdmoe_film_silu_bwd", du, de, g, u, e, N, HW, C, _dt(u))
         return du, de, None, None
+
+
+class _FilmReq:
+    __slots__ = ("emb", "p", "seed", "h")
+
+    def __init__(self, emb, p, seed):
+        self.emb, self.p, self.seed, self.h = emb, p, seed, None
+
+
+_FILM_REQ = None                                        # set around the mp_conv call of ops.mp_conv_film
+CONV_FILM = _os.environ.get("HDMOE_CONV_FILM", "1") != "0"
+CONV_FILM_TRAIN = _os.environ.get("HDMOE_CONV_FILM", "1") == "2"
+
+
+class _FilmDoneFn(torch.autograd.Function):
+    """film_silu whose forward was already computed by the producing conv's epilogue (h): only the backward is left."""
+
+    @staticmethod
+    def forward(ctx, u, e, p, seed, h):
+        ctx.pool_ok = not e.is_leaf
+        ctx.save_for_backward(u, e)
+        ctx.meta = (p, seed)
+        return h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _FilmSiluFn.backward(ctx, g) + (None,)
+
+
+def mp_conv_film(x: Tensor, weights, gain, emb: Tensor, p: float, training: bool, seg: Optional[Tensor] = None) -> Tensor:
+    """film_silu(mp_conv(x, weights, gain), emb, p) -- conv_res1 of Unet_block followed by FiLM, mp_silu and dropout (reference
+    model_components.py:240-246).  In the bf16 bank path the second step is an extra output of the conv kernel's epilogue."""
+    global _FILM_REQ
+    p = float(p) if training else 0.0
+    C = int((weights[0] if isinstance(weights, (list, tuple)) else weights).shape[0])
+    # Only without dropout (eval / sampling), unless forced (HDMOE_CONV_FILM=2): drawing the Philox bits in the conv epilogue -- 8 waves per CU,
+    # on every unit's critical path -- costs more than the whole separate pass (measured: conv6<2,1> 44 -> 85 us against a 22-us film kernel).
+    ok = (CONV_FILM and (p == 0.0 or CONV_FILM_TRAIN) and x.dtype == torch.bfloat16 and x.ndim == 4 and C % 8 == 0 and 256 % (C // 8) == 0
+          and _bank.ACTIVE is not None)
+    if not ok:
+        return film_silu(mp_conv(x, weights, gain, seg=seg, training=training), emb, p, training)
+    req = _FilmReq(_f32(emb), p, _next_seed() if p > 0.0 else 0)
+    _FILM_REQ = req
+    try:
+        y = mp_conv(x, weights, gain, seg=seg, training=training)
+    finally:
+        _FILM_REQ = None
+    if req.h is not None:
+        return _FilmDoneFn.apply(y, req.emb, p, req.seed, req.h)
+    return _FilmSiluFn.apply(y, req.emb, p, req.seed)
 
 
 def film_silu(u: Tensor, e: Tensor, p: float = 0.0, training: bool = False) -> Tensor:

@@ -149,8 +149,8 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
         skip_next = b0.conv_skip is not None
         x, h = ops.silu_branch(x, gx_scale=1.0 if skip_next else beta)     # main branch + skip / residual: one fused backward pass
         raw = not skip_next
-    y = conv("conv_res1", h, b0.conv_gain1)
-    y = ops.film_silu(y, emb, b0.dropout, tr)                 # FiLM * emb -> mp_silu -> F.dropout, one pass
+    # conv_res1 -> FiLM * emb -> mp_silu -> F.dropout: in the bf16 bank path the three elementwise steps are a second output of the conv's epilogue
+    y = ops.mp_conv_film(h, [b.conv_res1.weights for b in blocks], b0.conv_gain1, emb, b0.dropout, tr, seg=seg)
     if b0.type == "dec" and b0.conv_skip is not None:
         x = conv("conv_skip", x, alpha=beta)                   # beta folded into the skip projection's weight image
         return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=1.0)

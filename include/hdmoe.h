@@ -93,6 +93,11 @@ int hdmoe_conv_bwd6s(const void* x, const void* dy, const void* wd, void* dx, fl
  * GroupNorm + ReLU + AdaptiveAvgPool2d(1). */
 int hdmoe_conv_fwd_split_gn(const void* x, const void* w, void* y, const float* in_scale, const float* in_shift, int in_relu,
                             float* stats_ws, long wstride, long wplane, int N, int H, int W, int Cin, int Cout, float alpha, HS stream);
+/* k x k bf16 expert conv with the FiLM of Unet_block (mp_silu(y * emb) + dropout, model_components.py:242-246) as a second output of its
+ * epilogue; 1 = outside the fused kernel's domain, nothing launched. */
+int hdmoe_conv_fwd_film(const void* x, const void* w, void* y, void* h, const float* e, unsigned long long seed,
+                        const unsigned long long* seed_dev, float p, float alpha, const int* seg, int ngroups, long wstride, int N, int H, int W,
+                        int Cin, int Cout, const int* kh, const int* kw, const int* pt, const int* pl, int dtype, HS stream);
 int hdmoe_conv_split_stats_slots(int H, int W, int Cout);   /* partial-statistics slots per sample of hdmoe_conv_fwd_split_gn (0: outside its domain) */
 int hdmoe_gn1_finalize(float* scale, float* shift, float* mean, float* rstd, const float* ws, const float* gamma, const float* beta,
                        int N, int slots, int C, long count, float eps, HS stream);

@@ -1223,6 +1223,56 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k, bwd_bf16
         close_scaled(pg1[n], pg0[n], max(grel, 2e-4 if H < 64 else 1e-2), msg=n, atol=2e-6 * float(pg0[n].abs().max()) + 1e-9)
 
 
+@pytest.mark.parametrize("C,ks,train", [(32, [3, 5], True), (64, [3, 3, 5, 5], True), (32, [3], False)])
+def test_conv_with_film_epilogue_matches_the_two_launches(C, ks, train):
+    """ops.mp_conv_film (conv_res1 + FiLM + mp_silu + dropout of Unet_block, reference model_components.py:240-246): the elementwise
+    tail as a second output of the conv kernel's epilogue against conv followed by the film_silu kernel -- bit-identical outputs (same
+    arithmetic on the bf16-rounded conv result, same Philox bits) and identical gradients."""
+    import hdmoe_hip
+    from hdmoe_hip import ops, bank as wbank
+    torch.manual_seed(11)
+    G = len(ks)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(C, C, k, k)) for k in ks])
+    m = M().to(DEV)
+    N = 10
+    x = torch.randn(N, 32, 32, C, device=DEV).bfloat16()
+    emb = (1.0 + 0.3 * torch.randn(N, C, device=DEV))
+    cuts = sorted(torch.randint(0, N + 1, (G - 1,)).tolist())
+    seg = torch.tensor([0] + cuts + [N], dtype=torch.int32, device=DEV) if G > 1 else None
+    gy = torch.randn(N, 32, 32, C, device=DEV).bfloat16()
+    res = {}
+    saved = (ops.CONV_FILM, ops.CONV_FILM_TRAIN)
+    ops.CONV_FILM_TRAIN = True                                     # (with dropout the fused form is off by default: slower, see ops.mp_conv_film)
+    try:
+        for mode in ("warm", "fused", "separate"):
+            ops.CONV_FILM = mode != "separate"
+            hdmoe_hip.manual_seed(99)
+            wbank.bank_for(m).begin_step(False)
+            xx = x.clone().requires_grad_(True)
+            ee = emb.clone().requires_grad_(True)
+            out = ops.mp_conv_film(xx, list(m.ws), 0.8, ee, 0.2, train, seg=seg)
+            out.backward(gy)
+            wbank.deactivate()
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().clone(), xx.grad.clone(), ee.grad.clone(), [w.grad.clone() for w in m.ws])
+            for w in m.ws:
+                w.grad.zero_()
+    finally:
+        ops.CONV_FILM, ops.CONV_FILM_TRAIN = saved
+    (o1, dx1, de1, dw1), (o2, dx2, de2, dw2) = res["fused"], res["separate"]
+    assert torch.equal(o1, o2)
+    if train:
+        assert 0.1 < float((o1 == 0).float().mean()) < 0.3          # dropout 0.2 was applied
+    assert torch.equal(dx1, dx2)
+    close_scaled(de1, de2, 1e-5, msg="d emb")                      # (the FiLM backward sums over pixels with float atomics)
+    for a, b in zip(dw1, dw2):
+        close_scaled(a, b, 1e-5, msg="dw")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_silu_branch_and_cat_silu_match_the_separate_ops(dtype):
     """ops.silu_branch / ops.mp_cat_silu (decoder-block entry: the block input feeds mp_silu and the skip / residual path) against
