@@ -2,6 +2,7 @@
 //   pixel-norm  : normalize(x, dim=[1])            reference models/model_internals.py:8-30, model_components.py:238
 //   GroupNorm   : nn.GroupNorm(G, C) (+ReLU / +mp_silu fused)   model_components.py:102-109, :491, :530
 //   LayerNorm   : nn.LayerNorm(C)                  model_components.py:495-496, :645
+#include <stdlib.h>
 #include "common.h"
 #include "hdmoe.h"
 
@@ -809,7 +810,12 @@ static int groupnorm_bwd_impl(void* dx, float* dgamma, float* dbeta, float* ws, 
     const long nvec = n / VT<T>::W;
     hipLaunchKernelGGL(groupnorm_bwd_stats_vec_kernel<T>, dim3(N, parts), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const T*)dy, (const T*)x,
                        gamma, beta, mean, rstd, S, C, G, act, parts, dyb, dybs);
-    hipLaunchKernelGGL(groupnorm_bwd_apply_vec_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
+    // 512, not 2048 blocks: this pass belongs to the router trunks' backward, which has slack, and a chip-filling grid of it holds up the
+    // expert branch's kernels on the critical stream (same-box A/B 2048 -> 512: 15.52 -> 15.40 ms/step; the reverse experiment, four
+    // row-range blocks per sample in the statistics pass, cost +0.4 ms)
+    static const long gcap = getenv("HDMOE_GNB_GRID") ? atol(getenv("HDMOE_GNB_GRID")) : 512;
+    unsigned gb = grid_for(nvec); if (gb > gcap) gb = (unsigned)gcap;
+    hipLaunchKernelGGL(groupnorm_bwd_apply_vec_kernel<T>, dim3(gb), dim3(TPB), 0, stream, (T*)dx, (const T*)dy, (const T*)x,
                        gamma, beta, mean, rstd, s1, s2, S, C, G, act, nvec, dyb, dybs);
     return hdmoe_launch_status();
   })
