@@ -257,11 +257,7 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    if multi and os.environ.get("HDMOE_BENCH_EARLY_BARRIER", "0") == "1":
-        dist.barrier()
 
-    if os.environ.get("HDMOE_BENCH_UAF_PROBE", "0") == "1":
-        torch.cuda.memory._record_memory_history(enabled="all", context="alloc", stacks="python", max_entries=2000000)
     import hdmoe_hip
     from hdmoe_hip.dp import GradBuckets
     import configs as C
@@ -274,7 +270,7 @@ def main():
     lc = C.loss_configs
     crit = U.EDM_LOSS(num_experts=kw["num_experts"], sigma_data=kw["sigma_data"], Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"],
                       z_bal=lc["z_bal"], prior_bal=lc["prior_bal"])
-    buckets = GradBuckets(model, bucket_mb=16.0, force_collectives=force_dist and os.environ.get("HDMOE_BENCH_NO_FORCE_COLL", "0") != "1")            # flat fp32 grad buckets; RCCL all-reduce when world > 1
+    buckets = GradBuckets(model, bucket_mb=16.0, force_collectives=force_dist)            # flat fp32 grad buckets; RCCL all-reduce when world > 1
     zeta = 0.1
 
     from hdmoe_hip import ops
@@ -321,7 +317,6 @@ def main():
                 return {"loss": l}
 
     trace_loss = os.environ.get("HDMOE_BENCH_TRACE_LOSS", "0") == "1"    # diagnostic: the loss of every warm-up step (one sync each)
-    uaf_probe = os.environ.get("HDMOE_BENCH_UAF_PROBE", "0") == "1"      # diagnostic: who owned the small blocks a fresh allocation lands on?
     for _ in range(args.warmup):
         l = step()
         if trace_loss:
@@ -331,24 +326,8 @@ def main():
     # Collect now and keep the collector off inside the timed region (tensors are freed by reference counting).
     gc.collect()
     gc.disable()
-    if uaf_probe:
-        snap = torch.cuda.memory._snapshot()
-        events = [e for tr in snap["device_traces"] for e in tr]
-        probes = [torch.full((n,), 255, dtype=torch.uint8, device=device) for n in (1, 8, 64, 512, 513, 1024, 2048, 4096, 8192, 65536) for _ in range(4)]
-        torch.cuda.synchronize()
-        l = step()
-        print(f"[uaf] loss after poisoning the free small blocks: {float(l['loss']):.6g}", file=sys.stderr)
-        seen = set()
-        for t in probes:
-            ptr = t.data_ptr()
-            prev = [e for e in events if e.get("action") == "alloc" and e["addr"] <= ptr < e["addr"] + e["size"]]
-            if prev and ptr not in seen:
-                seen.add(ptr)
-                e = prev[-1]
-                fr = [f"{f['filename'].split('/')[-1]}:{f['line']}:{f['name']}" for f in e.get("frames", []) if "torch/" not in f["filename"]][:8]
-                print(f"[uaf] probe {t.numel()} B at {ptr:#x}: last owner {e['size']} B  <- " + " <- ".join(fr), file=sys.stderr)
     mem0 = torch.cuda.memory_allocated()
-    if multi and os.environ.get("HDMOE_BENCH_SKIP_BARRIER", "0") != "1":
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -381,6 +360,12 @@ def main():
     mem_growth = torch.cuda.memory_allocated() - mem0
     gc.enable()
     loss_val = float(loss["loss"].detach())
+    # sanity: EDM_LOSS clamps at 50 and random-init weights give ~4-5; anything else means the step computed garbage (this check caught a
+    # hipGraph memset-node hazard in round 2) -- said loudly, and recorded in the JSON line
+    import math
+    loss_ok = math.isfinite(loss_val) and 0.0 < loss_val < 49.0
+    if not loss_ok:
+        print(f"[bench] WARNING: implausible loss {loss_val!r} after the timed steps", file=sys.stderr)
 
     # second leg: the same step with MaskGenerator(step=0, BW=0.3) masks instead of all-ones -- routing restricted to
     # each sample's noise band.  The masks are graph inputs: copied into the captured tensors, no re-capture.
@@ -437,7 +422,7 @@ def main():
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if multi else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
+                       "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "loss_ok": loss_ok, "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
             "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "cpu_baseline": cpu,
