@@ -359,6 +359,13 @@ def main():
         graphed.timing = False
     mem_growth = torch.cuda.memory_allocated() - mem0
     gc.enable()
+    grads_equal = None
+    if multi and os.environ.get("HDMOE_BENCH_CHECK_RANKS", "0") == "1":
+        # after finish() every rank must hold the same averaged gradients, bit for bit (the replicas stay in sync without a broadcast)
+        cs = torch.stack([b.double().sum() for b in buckets.buckets] + [b.double().abs().sum() for b in buckets.buckets])
+        got = [torch.empty_like(cs) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, cs)
+        grads_equal = bool(all(torch.equal(t, got[0]) for t in got)) and bool(torch.isfinite(cs).all()) and float(cs[len(buckets.buckets):].sum()) > 0.0
     loss_val = float(loss["loss"].detach())
     # sanity: EDM_LOSS clamps at 50 and random-init weights give ~4-5; anything else means the step computed garbage (this check caught a
     # hipGraph memset-node hazard in round 2) -- said loudly, and recorded in the JSON line
@@ -410,7 +417,8 @@ def main():
         dist.barrier()
     if rank == 0:
         line = {
-            "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4),
+            # (an implausible loss means the step computed garbage: no headline number then, and a non-zero exit code below)
+            "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4) if loss_ok else None,
             "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bc["dtype"] == "bf16" else "f32",
             "data": "synthetic", "samples_per_sec": round(world * B * 1e3 / ms, 1),
@@ -422,7 +430,7 @@ def main():
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
                        + (" + RCCL grad all-reduce" if multi else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
-                       "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "loss_ok": loss_ok, "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
+                       "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "loss_ok": loss_ok, "grads_equal_across_ranks": grads_equal, "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
             "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "cpu_baseline": cpu,
@@ -431,6 +439,8 @@ def main():
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
+    if not loss_ok:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

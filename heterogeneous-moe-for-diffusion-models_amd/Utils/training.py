@@ -29,12 +29,16 @@ def build_optimizer(model: torch.nn.Module, optim_config: Dict[str, Any]) -> Fus
     scaling_net, log-var head) are not optimised."""
     net = model.net
     routers = list(net.Unet_router.parameters()) + list(net.vit_router.parameters())
-    return FusedAdamW([
+    opt = FusedAdamW([
         {"params": list(net.Unet_experts.parameters()), "lr": optim_config["lr_unet"]},
         {"params": list(net.VIT_experts.parameters()), "lr": optim_config["lr_vit"]},
         {"params": list(net.cross_attn.parameters()), "lr": optim_config["lr_attn"]},
         {"params": routers, "lr": optim_config["lr_router"]},
     ])
+    # an expert without a sample in a step is left out of that step's update, as in the reference (its .grad stays None there:
+    # models/model_config1.py:26-29, and torch.optim.AdamW skips grad-None tensors)
+    opt.track_expert_usage([net.Unet_experts, net.VIT_experts])
+    return opt
 
 
 def build_scheduler(optimizer: torch.optim.Optimizer, optim_config: Dict[str, Any]):

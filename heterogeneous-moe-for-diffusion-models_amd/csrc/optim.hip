@@ -9,6 +9,8 @@ namespace {
 
 struct __attribute__((aligned(8))) OptDesc {   // mirrored by hdmoe_hip/optim.py
   unsigned long long p, g, m, v;              // device addresses (m, v may be 0 for norm/scale-only tables)
+  unsigned long long step;                    // float: this tensor's own AdamW step count (torch.optim.AdamW keeps one per tensor), or 0
+  unsigned long long use;                     // float: > 0 when the tensor received a gradient this step (rows routed to its expert), or 0 = always
   long numel;
   int group, pad0;
 };
@@ -40,14 +42,27 @@ __global__ __launch_bounds__(256) void mt_scale_kernel(const OptDesc* descs, con
   const long i1 = i0 + OPT_CHUNK < d.numel ? i0 + OPT_CHUNK : d.numel;
   for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] *= coef;
 }
-struct AdamArgs { float lr[8], wd[8]; float beta1, beta2, eps, bc1, bc2_sqrt, max_norm; };
+struct AdamArgs { float lr[8], wd[8]; float beta1, beta2, eps, max_norm; };
+// A tensor whose expert received no sample this step is skipped altogether -- the reference leaves its .grad None and torch.optim.AdamW
+// then applies neither weight decay nor moment decay nor a step-count increment (reference model_config1.py:26-29 + Utils/training.py:195-197).
+__global__ __launch_bounds__(256) void mt_step_kernel(const OptDesc* descs, int ntensors) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntensors) return;
+  const OptDesc d = descs[t];
+  if (!d.step) return;
+  if (d.use && !(*(const float*)d.use > 0.f)) return;
+  *(float*)d.step += 1.f;
+}
 __global__ __launch_bounds__(256) void mt_adamw_kernel(const OptDesc* descs, const int2* chunks, const float* sumsq, AdamArgs a) {
-  const float coef = clip_coef(sumsq, a.max_norm);
   const int2 c = chunks[blockIdx.x];
   const OptDesc d = descs[c.x];
+  if (d.use && !(*(const float*)d.use > 0.f)) return;
+  const float coef = clip_coef(sumsq, a.max_norm);
   float* p = (float*)d.p; const float* g = (const float*)d.g; float* m = (float*)d.m; float* v = (float*)d.v;
   const float lr = a.lr[d.group], wd = a.wd[d.group];
-  const float step_size = lr / a.bc1;
+  const float step = *(const float*)d.step;                  // already advanced by mt_step_kernel
+  const float bc1 = 1.f - powf(a.beta1, step), bc2_sqrt = sqrtf(1.f - powf(a.beta2, step));
+  const float step_size = lr / bc1;
   const long i0 = (long)c.y * OPT_CHUNK;
   const long i1 = i0 + OPT_CHUNK < d.numel ? i0 + OPT_CHUNK : d.numel;
   for (long i = i0 + threadIdx.x; i < i1; i += 256) {
@@ -56,7 +71,7 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const OptDesc* descs, con
     const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
     const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    pi -= step_size * mi / (sqrtf(vi) / a.bc2_sqrt + a.eps);
+    pi -= step_size * mi / (sqrtf(vi) / bc2_sqrt + a.eps);
     p[i] = pi;
   }
 }
@@ -78,15 +93,15 @@ int hdmoe_mt_clip_scale(const void* descs, const int* chunks, int nchunks, const
   if (nchunks > 0) hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, (const OptDesc*)descs, (const int2*)chunks, sumsq, max_norm);
   return hdmoe_launch_status();
 }
-// lr / wd: host arrays of ngroups (<= 8) floats; sumsq may be NULL (no clipping)
-int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, const float* group_lr,
-                   const float* group_wd, int ngroups, float beta1, float beta2, float eps, int step, hipStream_t stream) {
-  if (ngroups < 1 || ngroups > 8 || step < 1) return HDMOE_EINVAL;
+// lr / wd: host arrays of ngroups (<= 8) floats; sumsq may be NULL (no clipping).  Every descriptor carries its tensor's step counter (device
+// float, advanced here) and optionally a "used this step" flag; bias corrections are computed on the device from the per-tensor count.
+int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, int ntensors, const float* sumsq, float max_norm, const float* group_lr,
+                   const float* group_wd, int ngroups, float beta1, float beta2, float eps, hipStream_t stream) {
+  if (ngroups < 1 || ngroups > 8 || ntensors < 0) return HDMOE_EINVAL;
   AdamArgs a;
   for (int i = 0; i < 8; ++i) { a.lr[i] = group_lr[i < ngroups ? i : 0]; a.wd[i] = group_wd[i < ngroups ? i : 0]; }
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
-  a.bc1 = 1.f - powf(beta1, (float)step);
-  a.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  if (ntensors > 0) hipLaunchKernelGGL(mt_step_kernel, dim3(cdiv(ntensors, 256)), dim3(256), 0, stream, (const OptDesc*)descs, ntensors);
   if (nchunks > 0) hipLaunchKernelGGL(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, stream, (const OptDesc*)descs, (const int2*)chunks, sumsq, a);
   return hdmoe_launch_status();
 }

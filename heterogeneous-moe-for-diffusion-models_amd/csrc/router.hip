@@ -180,6 +180,10 @@ __global__ void combine_rows_bwd_kernel(T* dys, float* dsparse, const T* dout, c
   }
 }
 
+__global__ void seg_counts_kernel(float* counts, const int* seg, int E) {
+  if ((int)threadIdx.x < E) counts[threadIdx.x] = (float)(seg[threadIdx.x + 1] - seg[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -200,6 +204,13 @@ int hdmoe_dispatch_plan(int* perm, int* row_expert, float* row_w, int* inv, int*
                         hipStream_t stream) {
   if (B < 1 || E < 1 || E > 64 || kcap < 1 || kcap > E) return HDMOE_EINVAL;
   hipLaunchKernelGGL(dispatch_plan_kernel, dim3(1), dim3(1024), 0, stream, perm, row_expert, row_w, inv, seg, sparse, B, E, kcap);
+  return hdmoe_launch_status();
+}
+// counts[e] = rows routed to expert e in this step (float): the optimizer skips the tensors of an expert without rows, like the reference,
+// whose `if not mask.any(): continue` leaves such an expert's gradients None (models/model_config1.py:26-29)
+int hdmoe_seg_counts(float* counts, const int* seg, int E, hipStream_t stream) {
+  if (!counts || !seg || E < 1 || E > 64) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(seg_counts_kernel, dim3(1), dim3(64), 0, stream, counts, seg, E);
   return hdmoe_launch_status();
 }
 int hdmoe_gather_rows(void* dst, const void* src, const int* perm, long R, long L, int dtype, hipStream_t stream) {
@@ -234,6 +245,6 @@ int hdmoe_combine_rows_bwd(void* dys, float* dsparse, const void* dout, const vo
   else return HDMOE_EDTYPE;
   return hdmoe_launch_status();
 }
-int hdmoe_version(void) { return 200; }
+int hdmoe_version(void) { return 300; }
 
 }  // extern "C"

@@ -258,7 +258,9 @@ class WeightBank:
         self._reduce_w6(None)
         ents = [e for e in self.entries.values() if e.ready]
         if any(e.done for e in ents):                        # some sections were finished on their own: only the rest
-            rest = [e for e in ents if not e.done]
+            # (an entry whose backward did not run has nothing to add, and its parameters may sit in a bucket that is already being
+            #  all-reduced beside this launch: the finish kernel's read-modify-write must not touch it)
+            rest = [e for e in ents if not e.done and e.used_bwd]
             if rest:
                 key = ("rest", tuple(id(e) for e in rest))
                 rows = self._stage_rows.get(key)

@@ -68,6 +68,19 @@ class GradBuckets:
             if cur:
                 self._seal(cur, n)
             self.tags = ["-"] * len(self.buckets)
+        # Per-expert routed-row counts of the step (written by the model's forward, read by FusedAdamW to skip experts without samples):
+        # one small tensor for all expert lists, summed over the ranks behind the last gradient bucket -- an expert is skipped only when no
+        # rank routed a sample to it.
+        self.usage = None
+        lists = [mod for name, mod in module.named_modules()
+                 if isinstance(mod, torch.nn.ModuleList) and name.rsplit(".", 1)[-1] in ("Unet_experts", "VIT_experts") and len(mod)]
+        if lists and self.buckets:
+            self.usage = torch.zeros(sum(len(l) for l in lists), dtype=torch.float32, device=self.buckets[0].device)
+            off = 0
+            for l in lists:
+                object.__setattr__(l, "_hdmoe_usage", self.usage[off:off + len(l)])
+                off += len(l)
+        self._usage_work = None
         self._pending = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
         self._next = 0                                             # collectives are issued strictly in bucket order
@@ -131,6 +144,8 @@ class GradBuckets:
             self._launch(self._next)
             self._next += 1
         self._next = 0
+        if self.usage is not None and (self.world > 1 or self.force):
+            dist.all_reduce(self.usage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
         for bi, w in enumerate(self._works):
             if w is not None:
                 w.wait()

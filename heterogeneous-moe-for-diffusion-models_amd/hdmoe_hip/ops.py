@@ -36,6 +36,12 @@ def _f32(t: Tensor) -> Tensor:
 
 _seed_state = {"seed": 0x5DEECE66D, "ctr": 0}
 
+# Host-side counters of which fused paths a step took ("trunk": fused router trunk forward, "bwd6" / "bwd6s": dgrad + wgrad in one
+# launch, "w6_defer": deferred wgrad6 reduction, "blk": fused Unet_block main branch): the parity tests assert that the path they
+# pin to the reference is the one the benchmark times.
+import collections as _collections
+STATS = _collections.Counter()
+
 
 def manual_seed(seed: int) -> None:
     """Seed of the device counter RNG used for dropout masks and router logit noise."""
@@ -286,19 +292,28 @@ def fanout(x: Tensor, n: int, scales=None):
 class _W6Arena:
     """Workspace of the DEFERRED wgrad6 reductions: every k x k layer of the weight bank keeps its partial slabs until the end of the
     backward pass, where one batched launch per 16 layers sums them (WeightBank._finish).  One bump-allocated buffer per device,
-    rewound at the start of a step; HDMOE_W6_ARENA_MB (default 8192) of the 288 GB."""
+    rewound at the start of a step.  It starts at HDMOE_W6_ARENA_MB (default 1024) and is re-sized to the step's high-water mark at the
+    next rewind outside a graph capture: a layer that does not fit meanwhile takes the non-deferred path (its own cached workspace)."""
 
     def __init__(self, device):
-        mb = int(_os.environ.get("HDMOE_W6_ARENA_MB", "8192"))
-        self.buf = torch.empty(mb << 18, dtype=torch.float32, device=device)
+        self.device = device
+        self.buf = torch.empty(int(_os.environ.get("HDMOE_W6_ARENA_MB", "1024")) << 18, dtype=torch.float32, device=device)
         self.off = 0
+        self.want = 0                                        # floats the current step would have needed
 
     def take(self, nfloats):
+        self.want = (self.want + 63) // 64 * 64 + nfloats    # advances whether or not the slice fits: the next rewind grows to it
         start = (self.off + 63) // 64 * 64
         if start + nfloats > self.buf.numel():
             return None
         self.off = start + nfloats
         return self.buf[start:start + nfloats]
+
+    def rewind(self):
+        if self.want > self.buf.numel() and not torch.cuda.is_current_stream_capturing():
+            self._old = getattr(self, "_old", []) + [self.buf]     # (a captured graph may still point into the old buffer: keep it alive)
+            self.buf = torch.empty(int(self.want * 1.25) // 64 * 64 + 64, dtype=torch.float32, device=self.device)
+        self.off = self.want = 0
 
 
 _w6_arenas = {}
@@ -309,7 +324,7 @@ BWD6 = _os.environ.get("HDMOE_BWD6", "1") != "0"          # dgrad + wgrad of a k
 def w6_arena_reset(device) -> None:
     a = _w6_arenas.get(torch.device(device))
     if a is not None:
-        a.off = 0
+        a.rewind()
 
 
 def _w6_arena_take(device, nfloats):
@@ -338,6 +353,7 @@ def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws
             if ws is not None:
                 if call("hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc, 1) == 0:
                     bank.defer_w6(list(Gs), seg, ws, [G, N, H, W, I, O, dtc, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
+                    STATS["w6_defer"] += 1
                     return
         if kib > 0:
             key = (x.device, torch.cuda.current_stream().stream_id)       # branches on different streams run concurrently
@@ -444,6 +460,7 @@ class _MPConvFn(torch.autograd.Function):
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, _dt(x), 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
+                    STATS["bwd6"] += 1
                 else:
                     dx = None
         if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and PROFILE is None and split and not ones and Ho == H and Wo == W
@@ -463,6 +480,7 @@ class _MPConvFn(torch.autograd.Function):
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, F32S, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
+                    STATS["bwd6s"] += 1
                 else:
                     dx = None
         if nig[0] and not fused:
@@ -1674,6 +1692,7 @@ class _TrunkFn(torch.autograd.Function):
             inp = y
         ctx.save_for_backward(x, *saved, *tensors)
         ctx.ents, ctx.bank = ents, bank
+        STATS["trunk"] += 1
         return out
 
     @staticmethod
@@ -1702,8 +1721,10 @@ class _TrunkFn(torch.autograd.Function):
             ent = ents[l]
             kib = lib().hdmoe_conv_wgrad6_ws_kib(1, N, H, W, I, O, k3, k3, F32S)
             arena = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
+            if arena is None and kib > 0 and not torch.cuda.is_current_stream_capturing():
+                arena = torch.empty(2 * kib * 256, dtype=torch.float32, device=x.device)      # arena exhausted (it grows at the next step): own slabs
             if arena is None:
-                raise RuntimeError("router trunk backward: no weight-gradient workspace (HDMOE_W6_ARENA_MB too small?)")
+                raise RuntimeError("router trunk backward: no weight-gradient workspace (arena exhausted inside a graph capture)")
             xin = x if l == 0 else saved[5 * (l - 1)]
             isc, ish = (None, None) if l == 0 else (saved[5 * (l - 1) + 1], saved[5 * (l - 1) + 2])
             da = torch.empty_like(xin)
@@ -1713,6 +1734,7 @@ class _TrunkFn(torch.autograd.Function):
                 raise RuntimeError("router trunk backward: layer outside the fused backward kernel's domain")
             bank.defer_w6(list(ent.G), None, arena, [1, N, H, W, I, O, F32S, 0, 3, 0, 0, 0, 0, 0, 0, 0])
             bank.note_backward(ent)
+            STATS["trunk_bwd"] += 1
         out = [da, None, None, None]
         for l in range(3):
             out += [None, ret[2 * l], ret[2 * l + 1]]
@@ -1732,7 +1754,12 @@ def trunk_ok(x: Tensor, convs) -> bool:
         if not _split_ok(probe, [w], False) or int(w.shape[1]) != c:
             return False
         c = int(w.shape[0])
-    return c % 4 == 0 and c <= 1024
+        # every layer's GroupNorm backward runs on the 16-byte-vector kernels only (the pooled-gradient form hdmoe_groupnorm_bwd_bcast has no
+        # scalar fallback): csrc/norm.hip gn_vec_ok -- C / 4 lanes per pixel must divide the 512-thread block
+        cv = c // 4
+        if c % 4 or cv > 512 or 512 % cv:
+            return False
+    return c <= 1024                                         # hdmoe_gn1_finalize_relu_mean: one pixel row of <= 1024 channels per pass
 
 
 def router_trunk(x: Tensor, convs, norms) -> Optional[Tensor]:

@@ -19,15 +19,17 @@ import torch
 
 from ._lib import call, lib
 
-_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("pad0", "<i4")])
+_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("step", "<u8"), ("use", "<u8"), ("numel", "<i8"), ("group", "<i4"),
+                  ("pad0", "<i4")])
 _CHUNK = 4096
 
 
 class _Table:
     """Device-side (tensor, chunk) table over a list of parameters that currently have gradients."""
 
-    def __init__(self, entries):
-        """entries: list of (param, grad, m or None, v or None, group)"""
+    def __init__(self, entries, steps=None, uses=None):
+        """entries: list of (param, grad, m or None, v or None, group); steps: per-entry device float step counters; uses: per-entry device
+        address of a float "received a gradient this step" flag (0 = always)."""
         assert lib().hdmoe_opt_desc_bytes() == _DESC.itemsize
         dev = entries[0][0].device
         descs = np.zeros(len(entries), dtype=_DESC)
@@ -36,12 +38,15 @@ class _Table:
             d = descs[i]
             d["p"], d["g"] = p.data_ptr(), g.data_ptr()
             d["m"], d["v"] = (0 if m is None else m.data_ptr()), (0 if v is None else v.data_ptr())
+            d["step"] = 0 if steps is None else steps[i].data_ptr()
+            d["use"] = 0 if uses is None else uses[i]
             d["numel"], d["group"] = p.numel(), grp
             chunks.extend((i, c) for c in range((p.numel() + _CHUNK - 1) // _CHUNK))
         self.descs = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
         self.n = len(chunks)
-        self.sig = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _, _ in entries)
+        self.ntensors = len(entries)
+        self.sig = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _, _ in entries) + tuple(uses or ())
 
 
 _norm_tables = {}
@@ -92,11 +97,13 @@ def _sqrt_scalar(ss: torch.Tensor) -> torch.Tensor:
 class FusedAdamW(torch.optim.Optimizer):
     """AdamW over all parameters in two launches (global-norm clip + update), ``torch.optim.AdamW``'s state_dict layout.
 
-    Semantics where it differs from the reference loop (Utils/training.py:55-65,195-197): bias correction uses ONE step counter for all
-    tensors (torch keeps one per tensor; identical whenever every tensor receives a gradient from step 1, which the flat gradient
-    buckets guarantee: a never-routed expert's gradient is an exact zero, not None), so an expert that got no sample in a step
-    still sees weight decay and moment decay in that step -- the DDP-like behaviour of gradient-as-bucket-view training, whereas the
-    reference's `if not mask.any(): continue` leaves its grad None and AdamW skips it."""
+    Every tensor keeps its own step counter (``state[p]["step"]``, a device float as in torch's capturable mode) and the bias corrections
+    are computed from it on the device.  An expert that received no sample in a step has ``.grad is None`` in the reference
+    (`if not mask.any(): continue`, models/model_config1.py:26-29) and torch.optim.AdamW then skips its tensors: no weight decay, no
+    moment decay, no step increment (Utils/training.py:195-197).  Here such an expert's gradient is an exact zero in its flat-bucket
+    view instead, so the skip is driven by the dispatch plan: ``track_expert_usage`` registers the expert lists, the model's forward
+    leaves the per-expert routed-row counts of the step in ``<ModuleList>._hdmoe_usage`` (device floats; averaged over the ranks
+    with the gradients, hdmoe_hip/dp.py), and the update kernel skips a tensor whose expert's count is 0."""
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) > 8:
@@ -104,7 +111,23 @@ class FusedAdamW(torch.optim.Optimizer):
         if len({tuple(g["betas"]) for g in self.param_groups}) > 1 or len({g["eps"] for g in self.param_groups}) > 1:
             raise ValueError("FusedAdamW needs the same betas/eps in every group (lr and weight_decay may differ)")
         self._table = None
-        self._step = 0
+        self._usage = {}                                     # id(param) -> (expert ModuleList, expert index)
+
+    def track_expert_usage(self, expert_lists) -> None:
+        """``expert_lists``: ModuleLists of experts (HDMOEM.Unet_experts / VIT_experts).  Their parameters are updated only in steps in
+        which the expert received at least one sample (on any rank)."""
+        for lst in expert_lists:
+            for e, expert in enumerate(lst):
+                for p in expert.parameters():
+                    self._usage[id(p)] = (lst, e)
+        self._table = None
+
+    def _use_ptr(self, p) -> int:
+        src = self._usage.get(id(p))
+        if src is None:
+            return 0
+        u = getattr(src[0], "_hdmoe_usage", None)            # written by the model's forward (models/_assembly.py _dispatch_nhwc)
+        return 0 if u is None else u.data_ptr() + 4 * src[1]
 
     def zero_grad(self, set_to_none: bool = False):
         """Zero the gradients IN PLACE.  torch's default (set_to_none=True) would detach the flat DP bucket views / the weight bank's
@@ -125,13 +148,16 @@ class FusedAdamW(torch.optim.Optimizer):
                     continue
                 st = self.state[p]
                 if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif st["step"].device != p.device or st["step"].dtype != torch.float32:   # a checkpoint written by torch.optim.AdamW (host counters)
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
                 ents.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], gi))
-        sig = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _, _ in ents)
+        uses = tuple(self._use_ptr(p) for p, *_ in ents)
+        sig = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _, _ in ents) + uses
         if self._table is None or self._table.sig != sig:
-            self._table = _Table(ents) if ents else None
+            self._table = _Table(ents, [self.state[p]["step"] for p, *_ in ents], uses) if ents else None
         return ents
 
     @torch.no_grad()
@@ -142,21 +168,16 @@ class FusedAdamW(torch.optim.Optimizer):
         ents = self._ensure_state()
         if not ents:
             return loss
-        self._step += 1
-        for p, *_ in ents:
-            self.state[p]["step"] += 1
         ss, max_norm = None, 0.0
         if clip is not None:
             ss, _ = grad_norm_sq(clip[0], key=("step", id(self)))
             max_norm = float(clip[1])
         g0 = self.param_groups[0]
-        call("hdmoe_mt_adamw", self._table.descs, self._table.chunks, self._table.n, ss, max_norm,
+        call("hdmoe_mt_adamw", self._table.descs, self._table.chunks, self._table.n, self._table.ntensors, ss, max_norm,
              [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups], len(self.param_groups),
-             g0["betas"][0], g0["betas"][1], g0["eps"], self._step)
+             g0["betas"][0], g0["betas"][1], g0["eps"])
         return loss
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = [int(st["step"]) for st in self.state.values() if "step" in st]
-        self._step = max(steps) if steps else 0
         self._table = None

@@ -33,8 +33,22 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
     """x channel-last (B,H,W,C) -> (B,H,W,C).  ``stager``: cut the autograd graph between the bank and the combine (staged step)."""
     mods = list(experts)
     E = len(mods)
+
+    def note_usage(plan):
+        # rows routed to each expert this step, for the optimizer: an expert without a sample is left out of the update like a grad-None
+        # tensor in the reference loop (hdmoe_hip/optim.py FusedAdamW.track_expert_usage)
+        if torch.is_grad_enabled() and isinstance(experts, nn.ModuleList):
+            u = getattr(experts, "_hdmoe_usage", None)
+            if u is None or u.device != x.device or u.numel() != E:
+                if torch.cuda.is_current_stream_capturing():
+                    return
+                u = torch.zeros(E, dtype=torch.float32, device=x.device)
+                object.__setattr__(experts, "_hdmoe_usage", u)
+            ops.call("hdmoe_seg_counts", u, plan.seg, E)
+
     if all(isinstance(e, m.Unet_expert) for e in mods) and E <= 8:
         plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
+        note_usage(plan)
         xs = ops.gather_rows(x, plan)
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
@@ -44,6 +58,7 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         return ops.combine_rows(ys, out_router, plan)
     if VIT_BANK and m.vit_bank_compatible(mods, x.shape[1], x.shape[2]):
         plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
+        note_usage(plan)
         xs = ops.gather_rows(x, plan)
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)

@@ -411,6 +411,12 @@ def vit_bank_compatible(experts: Sequence[nn.Module], H: int, W: int) -> bool:
                 None if e.map_txt is None else tuple(e.map_txt.weights.shape))
     if any(sig(e) != sig(e0) for e in experts) or b0 is None or any(b.resample != "keep" for b in e0.diffit):
         return False
+    # domains of the ragged kernels (csrc/ragged.hip, attn_rag_* in csrc/attention.hip): outside them the per-expert path runs instead
+    heads = b0.TMSA.num_heads
+    if e0.emb_dim > 256 or b0.GN.num_groups > 32 or e0.emb_dim % heads or (e0.emb_dim // heads) not in (1, 2, 4, 8, 16, 32):
+        return False
+    if 2 * max(e.seq_ln for e in experts) * (e0.emb_dim // heads) * 4 > 60 * 1024:      # K / V of one (row, head) in LDS
+        return False
     for e in experts:
         p = e.patch.kernel_size[0]
         L = (-(-H // p)) * (-(-W // p))

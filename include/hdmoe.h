@@ -269,6 +269,8 @@ int hdmoe_router_head_bwd(float* dlogits, const float* dsparse, const float* dpr
                           HS stream);
 int hdmoe_dispatch_plan(int* perm, int* row_expert, float* row_w, int* inv, int* seg, const float* sparse, int B, int E,
                         int kcap, HS stream);
+/* counts[e] = seg[e+1] - seg[e] as float: rows routed to expert e this step (read by hdmoe_mt_adamw's `use` flags) */
+int hdmoe_seg_counts(float* counts, const int* seg, int E, HS stream);
 int hdmoe_gather_rows(void* dst, const void* src, const int* perm, long R, long L, int dtype, HS stream);
 int hdmoe_combine_rows_fwd(void* out, const void* ys, const int* inv, const float* row_w, long B, int kcap, long L,
                            int dtype, HS stream);
@@ -285,13 +287,16 @@ int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU
                        const float* rV, int B, long L, int E, float unet_bal, float vit_bal, float z_bal, HS stream);
 
 /* ---- N3: fused multi-tensor clip_grad_norm_ + AdamW  (Utils/training.py:55-65,195-197) ----------------------------------- */
-/* descs: device array of {p, g, m, v addresses, numel, group} (hdmoe_opt_desc_bytes() bytes each); chunks: device int32 pairs
- * (descriptor index, 4096-element chunk index).  The clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) is read on the device. */
+/* descs: device array of {p, g, m, v, step, use addresses, numel, group} (hdmoe_opt_desc_bytes() bytes each); chunks: device int32 pairs
+ * (descriptor index, 4096-element chunk index).  The clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) is read on the device.
+ * step: the tensor's own AdamW step count (device float, advanced by hdmoe_mt_adamw); use: device float, > 0 when the tensor received a
+ * gradient this step, or 0 = always -- a tensor of an expert that got no sample is skipped like a grad-None tensor in torch.optim.AdamW
+ * (reference models/model_config1.py:26-29 leaves such an expert out of the graph; Utils/training.py:195-197). */
 int hdmoe_opt_desc_bytes(void);
 int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, HS stream);
 int hdmoe_mt_clip_scale(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, HS stream);
-int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, const float* group_lr,
-                   const float* group_wd, int ngroups, float beta1, float beta2, float eps, int step, HS stream);
+int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, int ntensors, const float* sumsq, float max_norm, const float* group_lr,
+                   const float* group_wd, int ngroups, float beta1, float beta2, float eps, HS stream);
 
 #undef HS
 #ifdef __cplusplus

@@ -1,0 +1,180 @@
+"""The path bench.py TIMES, pinned to the reference directly.
+
+From the second step on every conv weight goes through the weight bank (hdmoe_hip/bank.py): the fused dgrad + wgrad launches
+(csrc/bwd6.hip), the deferred batched weight-gradient reduction, the fused router trunk (ops._TrunkFn) and -- in bench.py -- the staged
+hipGraph replay (hdmoe_hip/graph.py) only run then.  The reference fixtures at real widths (tests/golden/wide_config{1..4}.pt, written by
+oracle/make_golden.py from the reference's own modules) are therefore compared with the LAST of several identical steps here:
+outputs, router top-k indices (exact), x.grad and the 18 stored parameter gradients, in fp32 and in bf16 compute mode, with both
+arithmetic variants of the router-trunk backward, eagerly and through the staged replay in train() mode (dropout p = 0, zeta = 0 --
+the forced weight re-normalisation of train mode moves a conv weight by ~eps * |1 - rms| ~ 4e-6 relative, far inside the tolerances).
+
+bf16 tolerances (relative to each tensor's max): `denoised` 2e-2; `out_gate` -- a per-pixel 2-way softmax of gate logits
+computed from bf16 features -- 6e-2; parameter / input gradients 6e-2.  Measured values are written to gpurun_out/bench_path_parity.json.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_measured = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import hdmoe_hip
+    hdmoe_hip.lib()
+    yield
+    hdmoe_hip.set_compute_dtype(torch.float32)
+    if _measured:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_path_parity.json"), "w") as f:
+            json.dump(_measured, f, indent=1, sort_keys=True)
+
+
+def _rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin), "non-finite pattern differs"
+    if not bool(fin.any()):
+        return 0.0
+    return float((a[fin] - b[fin]).abs().max()) / max(float(b[fin].abs().max()), 1e-30)
+
+
+def _check(g, kw, out, xgrad, pg, tol_out, tol_gate, tol_grad, tag):
+    """Outputs / indices / gradients of one step against the reference fixture; returns the measured relative errors."""
+    k = kw["top_k"]
+    errs = {}
+    for key in ("Unet_raw", "vit_raw"):                        # router indices bit-exact vs the reference
+        got = out[key].detach().float().cpu()
+        assert torch.equal(torch.topk(got, k, dim=-1).indices, g["topk_idx"][key]), f"{tag}: {key} top-k indices"
+        fin = torch.isfinite(g["out"][key])
+        errs[f"max_abs_dlogit_{key}"] = float((got[fin] - g["out"][key][fin]).abs().max())
+        errs[f"min_topk_margin_{key}"] = float(g["topk_margin"][key].min())
+        assert errs[f"max_abs_dlogit_{key}"] < 0.01 * errs[f"min_topk_margin_{key}"], (tag, key, errs)
+    for key, ref in g["out"].items():
+        if ref is None:
+            continue
+        e = errs[f"out_{key}"] = _rel_err(out[key], ref)
+        tol = tol_gate if key == "out_gate" else (1e-3 if key in ("Unet_raw", "vit_raw", "Unet_router_loss", "vit_router_loss") else tol_out)
+        assert e <= tol, f"{tag}: {key} rel err {e:.3e} > {tol:.1e}"
+    errs["x_grad"] = _rel_err(xgrad, g["x_grad"])
+    assert errs["x_grad"] <= tol_grad, f"{tag}: x_grad {errs['x_grad']:.3e}"
+    for n, gref in g["param_grads"].items():
+        e = errs[f"grad_{n}"] = _rel_err(pg[n], gref)
+        assert e <= tol_grad, f"{tag}: grad {n} rel err {e:.3e} > {tol_grad:.1e}"
+    return errs
+
+
+def _setup(g, dtype, train=False):
+    import hdmoe_hip
+    from conftest import wide_setup
+    hdmoe_hip.set_compute_dtype(dtype)
+    variant, model, kw, state, inp = wide_setup(g)
+    model.load_state_dict(state)
+    model = model.to(DEV)
+    if train:
+        model.train()
+        for mod in model.modules():                            # train-mode kernels (weight mutation, Philox paths with p = 0) without randomness
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+                mod.dropout = 0.0
+    else:
+        model.eval()
+    inp = {k_: v.to(DEV) for k_, v in inp.items()}
+    return model, kw, inp
+
+
+MODES = [("fp32", torch.float32, True, 1e-4, 1e-4, 3e-4), ("bf16_trunkbwd_bf16", torch.bfloat16, True, 2e-2, 6e-2, 6e-2),
+         ("bf16_trunkbwd_3prod", torch.bfloat16, False, 2e-2, 6e-2, 6e-2)]
+
+
+@pytest.mark.parametrize("mode,dtype,trunk_bf16,tol_out,tol_gate,tol_grad", MODES, ids=[m[0] for m in MODES])
+def test_bank_path_third_step_matches_the_reference(golden_wide, mode, dtype, trunk_bf16, tol_out, tol_gate, tol_grad):
+    import hdmoe_hip
+    from hdmoe_hip import ops
+    from Utils.utils import EDM_LOSS
+    g = golden_wide
+    prev = ops.TRUNK_BWD_BF16
+    ops.TRUNK_BWD_BF16 = trunk_bf16
+    try:
+        model, kw, inp = _setup(g, dtype)
+        lc = g["loss_cfg"]
+        crit = EDM_LOSS(num_experts=kw["num_experts"], sigma_data=0.5, Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"], z_bal=lc["z_bal"], prior_bal=0.0)
+        for it in range(3):
+            model.zero_grad(set_to_none=False)
+            ops.STATS.clear()
+            x = inp["x"].clone().requires_grad_(True)
+            out = model(x=x, sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["unet_mask"], Vit_router_mask=inp["vit_mask"],
+                        zeta=0.0, return_log_var=True, **g["extra"])
+            loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+            loss["loss"].backward()
+        torch.cuda.synchronize()
+        bank = model._hdmoe_bank
+        assert len(bank.entries) > 100 and all(e.ready for e in bank.entries.values())
+        if dtype == torch.bfloat16:                            # the kernels bench.py times ran in THIS step
+            assert ops.STATS["trunk"] == 2 and ops.STATS["trunk_bwd"] == 6, dict(ops.STATS)
+            assert ops.STATS["bwd6"] + ops.STATS["blk_bwd"] >= 10 and ops.STATS["w6_defer"] + ops.STATS["bwd6"] + ops.STATS["blk_bwd"] >= 20, dict(ops.STATS)
+        torch.testing.assert_close(loss["loss"].detach().cpu(), g["loss"]["loss"], rtol=10 * tol_out, atol=1e-4)
+        pg = {n: p.grad for n, p in model.named_parameters()}
+        _measured[f"eager_cfg{g['cfg_id']}_{mode}"] = _check(g, kw, out, x.grad, pg, tol_out, tol_gate, tol_grad, f"cfg{g['cfg_id']} {mode}")
+    finally:
+        ops.TRUNK_BWD_BF16 = prev
+        hdmoe_hip.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("split_router", [True, False], ids=["ten_graphs", "seven_graphs"])
+def test_staged_train_mode_replay_matches_the_reference(golden_wide, split_router):
+    """What bench.py replays: the StagedStep of a train()-mode model in bf16 compute mode (dropout p = 0 and zeta = 0 so that the
+    reference's eval-mode fixture applies), three replays, against the reference fixture."""
+    import hdmoe_hip
+    from hdmoe_hip import ops, graph as hgraph
+    from hdmoe_hip.dp import GradBuckets
+    from Utils.utils import EDM_LOSS
+    g = golden_wide
+    if g["cfg_id"] == 4 and not split_router:
+        pytest.skip("one staged variant is enough for the 64x64 fixture")
+    try:
+        model, kw, inp = _setup(g, torch.bfloat16, train=True)
+        lc = g["loss_cfg"]
+        crit = EDM_LOSS(num_experts=kw["num_experts"], sigma_data=0.5, Unet_bal=lc["unet_bal"], vit_bal=lc["vit_bal"], z_bal=lc["z_bal"], prior_bal=0.0)
+        buckets = GradBuckets(model)
+        x = inp["x"].clone().requires_grad_(True)
+        keep = {}
+
+        def fwd_bwd():
+            buckets.zero_grad()
+            if x.grad is not None:
+                x.grad.zero_()
+            out = model(x=x, sigma=inp["sigma"], text_emb=inp["text"], Unet_router_mask=inp["unet_mask"], Vit_router_mask=inp["vit_mask"],
+                        zeta=0.0, return_log_var=True, **g["extra"])
+            loss = crit(sigma_vec=inp["sigma"], x=inp["x0"], sigma=inp["sigma"], out_model=out)
+            hgraph.backward(loss["loss"])
+            keep["out"] = {k_: (None if v is None else v.detach()) for k_, v in out.items()}
+            return loss["loss"].detach()
+
+        saved = hgraph.Stager.SPLIT_ROUTER
+        hgraph.Stager.SPLIT_ROUTER = split_router
+        try:
+            ops.STATS.clear()
+            staged = hgraph.StagedStep(fwd_bwd, DEV, warmup=2)
+        finally:
+            hgraph.Stager.SPLIT_ROUTER = saved
+        assert staged.split_router == split_router
+        assert ops.STATS["trunk"] >= 4 and ops.STATS["bwd6"] + ops.STATS["blk_bwd"] >= 10, dict(ops.STATS)      # warm-up step 2 and the capture ran the fused paths
+        for _ in range(3):
+            l_g = staged()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(l_g.cpu(), g["loss"]["loss"], rtol=0.2, atol=1e-4)
+        pg = {n: p.grad for n, p in model.named_parameters()}
+        tag = f"staged_cfg{g['cfg_id']}_{'ten' if split_router else 'seven'}_graphs"
+        _measured[tag] = _check(g, kw, keep["out"], x.grad, pg, 2e-2, 6e-2, 6e-2, tag)
+    finally:
+        hdmoe_hip.set_compute_dtype(torch.float32)

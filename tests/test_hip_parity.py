@@ -924,6 +924,45 @@ def test_fused_adamw_and_clip_match_torch():
     close(sd["state"][1]["exp_avg_sq"], ref_o.state_dict()["state"][1]["exp_avg_sq"], rtol=1e-4, atol=1e-8)
 
 
+def test_fused_adamw_skips_experts_without_samples():
+    """Reference semantics (models/model_config1.py:26-29 + Utils/training.py:195-197): an expert that received no sample in a step is
+    not part of the graph, its parameters' .grad stay None and torch.optim.AdamW skips them -- no weight decay, no moment decay, no
+    step increment, and later bias corrections use the tensor's OWN step count.  The HIP path has exact-zero gradients in the flat
+    buckets instead and skips on the per-expert routed-row counts of the dispatch plan (FusedAdamW.track_expert_usage)."""
+    from hdmoe_hip.optim import FusedAdamW
+    torch.manual_seed(3)
+    mk = lambda: torch.nn.ModuleList([torch.nn.Linear(5, 7) for _ in range(3)])
+    ref_m = mk()
+    dev_m = mk()
+    dev_m.load_state_dict(ref_m.state_dict())
+    dev_m = dev_m.to(DEV)
+    shared_r, shared_d = torch.nn.Parameter(torch.randn(9)), None
+    shared_d = torch.nn.Parameter(shared_r.detach().clone().to(DEV))
+    ref_o = torch.optim.AdamW([{"params": list(ref_m.parameters()), "lr": 1e-2, "weight_decay": 0.1}, {"params": [shared_r], "lr": 3e-3}])
+    dev_o = FusedAdamW([{"params": list(dev_m.parameters()), "lr": 1e-2, "weight_decay": 0.1}, {"params": [shared_d], "lr": 3e-3}])
+    dev_o.track_expert_usage([dev_m])
+    usage = torch.zeros(3, device=DEV)
+    object.__setattr__(dev_m, "_hdmoe_usage", usage)
+    for it, used in enumerate([(4, 0, 2), (1, 3, 0), (0, 0, 5), (2, 2, 2)]):
+        usage.copy_(torch.tensor(used, dtype=torch.float32))
+        for e in range(3):
+            for rp, dp in zip(ref_m[e].parameters(), dev_m[e].parameters()):
+                if used[e]:
+                    g = torch.randn(rp.shape)
+                    rp.grad, dp.grad = g.clone(), g.clone().to(DEV)
+                else:
+                    rp.grad, dp.grad = None, torch.zeros(rp.shape, device=DEV)       # reference: None; buckets: exact zeros
+        g = torch.randn(9)
+        shared_r.grad, shared_d.grad = g.clone(), g.clone().to(DEV)
+        ref_o.step(); dev_o.step()
+        for e in range(3):
+            for rp, dp in zip(ref_m[e].parameters(), dev_m[e].parameters()):
+                close(dp, rp, rtol=2e-5, atol=1e-6, msg=f"expert {e} after step {it}")
+        close(shared_d, shared_r, rtol=2e-5, atol=1e-6)
+    steps = [float(dev_o.state[next(dev_m[e].parameters())]["step"]) for e in range(3)]
+    assert steps == [3.0, 2.0, 3.0] and float(dev_o.state[shared_d]["step"]) == 4.0
+
+
 def test_trainer_iteration_and_checkpoint_roundtrip(tmp_path):
     """Reference training.py:110-197 iteration order on the HIP path + the checkpoint dictionary of :242-271: the file
     restores model and optimizer exactly, and its optimizer state also loads into torch.optim.AdamW (reference optimizer)."""
