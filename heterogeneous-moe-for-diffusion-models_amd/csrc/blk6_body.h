@@ -1,0 +1,465 @@
+// Device body of the fused Unet_block main branch (blk6.hip has the design notes and the launch code):
+//   y = alpha * convB( mid( convA(x) ) ) + beta * res        with the intermediate tile kept in LDS.
+// Forward  (mode 0): convA = conv_res1, mid = dropout_p(mp_silu(u * e[n][c])), convB = conv_res2 (+ mp_sum with the residual).
+// Backward (mode 1): convA = dgrad of conv_res2, mid = FiLM / mp_silu / dropout backward, convB = dgrad of conv_res1.
+// The LDS images, the DMA pieces, the swizzle and the MFMA tap loop are those of conv6_body.h.
+#pragma once
+#include "common.h"
+#include "conv6_common.h"
+
+namespace {
+
+struct B6Args {
+  const void* x;                      // [N][H][W][Ca] bf16: input of conv A
+  const void* wa;                     // [g][tap][Cm][Ca] bf16
+  const void* wb;                     // [g][tap][Cb][Cm] bf16
+  void* y;                            // [N][H][W][Cb]
+  const void* res;                    // optional [N][H][W][Cb]
+  const int* seg;
+  long wa_stride, wb_stride;          // elements per group
+  int N, H, W, Ca, Cm, Cb, ngroups;
+  int ks[HDMOE_MAX_GROUPS], order[HDMOE_MAX_GROUPS];
+  float alpha, beta;                  // epilogue of conv B
+  float alpha_mid;                    // scale of conv A's accumulator
+  int TH, tpi;                        // tile rows (TH * W = 256 output pixels), tiles per image
+  int T;                              // taps per weight stage
+  int xb_bytes, hb_plane, wb_bytes;   // one x-chunk buffer / one 32-channel plane of the intermediate / one weight stage buffer
+  int xbytes, wabytes, wbbytes;       // buffer-descriptor extents
+  unsigned m_tpi, m_T;                // 2^32 / d + 1 reciprocals
+  int mode;                           // 0: FiLM forward, 1: FiLM backward
+  const float* e;                     // [N][Cm] fp32 FiLM vector 1 + emb_layer(e) * gain
+  void* u;                            // [N][H][W][Cm]: mode 0 OUT conv A's output (pre-activation); mode 1 IN the saved pre-activation
+  void* hmid;                         // [N][H][W][Cm]: mode 0 OUT the activation (input of conv B, saved for its weight gradient); mode 1 OUT du
+  float* de;                          // mode 1: [N][Cm] += sum over pixels of d(mid)/d(e)
+  const unsigned long long* seed_dev; unsigned seed_lo, seed_hi; float p;
+};
+
+struct B6Unit { int g, ks, pd, ntaps, ntg, WXp, HX, HM, ppt, nblkA, n, ty0; };
+
+template <int NTM, int NTB>
+DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int NW = 8;
+  constexpr int NBM = 32 * NTM, NBB = 32 * NTB;
+  constexpr int PPTA = NBM / 16, PPTB = NBB / 16;
+  constexpr int NPW = 6;                        // x pieces per wave (<= 48 pieces of 16 pixels per chunk)
+  constexpr int NWP = 5;                        // weight pieces per wave per stage (T * NB / 16 <= 40)
+  constexpr int SPT = 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int csl = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  const int prow = lane >> 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wa), 0, a.wabytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wb), 0, a.wbbytes, 0x00020000);
+
+  uint32_t seed_lo = a.seed_lo, seed_hi = a.seed_hi;
+  if (a.p > 0.f) mix_seed(seed_lo, seed_hi, a.seed_dev);
+  const float drop_inv = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+
+  // ---- unit list (as conv6_body.h): groups in descending kernel size; a unit = one TH x W tile of one routed row
+  const int oi_l = lane & 7;
+  int v_g = 0, v_ks = 0;
+#pragma unroll
+  for (int oi = 0; oi < HDMOE_MAX_GROUPS; ++oi) v_g = (oi_l == oi) ? a.order[oi] : v_g;
+#pragma unroll
+  for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) v_ks = (v_g == g) ? a.ks[g] : v_ks;
+  const bool slot_ok = lane < a.ngroups;
+  const int v_row0 = (a.seg && slot_ok) ? a.seg[v_g] : 0;
+  const int v_rows = !slot_ok ? 0 : (a.seg ? a.seg[v_g + 1] - v_row0 : a.N);
+  const int v_units = v_rows * a.tpi;
+  int v_ustart = v_units;
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const int o = __shfl_up(v_ustart, d, 8);
+    if (oi_l >= d) v_ustart += o;
+  }
+  const int total = __builtin_amdgcn_readlane(v_ustart, 7);
+  v_ustart -= v_units;
+  auto udiv = [](int x, unsigned magic, int d) {
+    int q = (int)(((unsigned long long)(unsigned)x * magic) >> 32);
+    if (q * d > x) --q;
+    if ((q + 1) * d <= x) ++q;
+    return q;
+  };
+  auto decode = [&](int j, B6Unit& u) {
+    const unsigned long long hit = __ballot(lane < 8 && j >= v_ustart && j < v_ustart + v_units);
+    const int slot = (int)__builtin_ctzll(hit | (1ull << 7));
+    const int uu = j - __builtin_amdgcn_readlane(v_ustart, slot);
+    const int row0 = __builtin_amdgcn_readlane(v_row0, slot);
+    u.g = __builtin_amdgcn_readlane(v_g, slot); u.ks = __builtin_amdgcn_readlane(v_ks, slot);
+    u.pd = (u.ks - 1) >> 1; u.ntaps = u.ks * u.ks; u.ntg = udiv(u.ntaps + a.T - 1, a.m_T, a.T);
+    u.WXp = a.W + u.ks - 1; u.HX = a.TH + 2 * (u.ks - 1); u.HM = a.TH + u.ks - 1;
+    u.ppt = (u.WXp * u.HX + 15) >> 4;
+    u.nblkA = (u.HM * a.W) >> 5;
+    const int img = udiv(uu, a.m_tpi, a.tpi);
+    u.n = row0 + img; u.ty0 = (uu - img * a.tpi) * a.TH;
+  };
+
+  // ---- x pieces (16 pixels x 32 channels of one chunk) of the unit's (HX x WXp) input region; ~0 = padding (the DMA writes zeros)
+  unsigned hyx[NPW];
+  int hyx_ks = -1;
+  auto hyx_update = [&](const B6Unit& u) {
+    if (u.ks == hyx_ks) return;
+    hyx_ks = u.ks;
+    const int magic = (1 << 20) / u.WXp + 1;
+    const int npx = u.WXp * u.HX;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int pi = wave + NW * k;
+      const int px = 16 * pi + prow;
+      int hy = (int)(((unsigned)px * (unsigned)magic) >> 20);
+      if (hy * u.WXp > px) --hy;
+      const int hx = px - hy * u.WXp;
+      hyx[k] = (pi < u.ppt && px < npx) ? (unsigned)((hy << 8) | hx) : 0xFFFFFFFFu;
+    }
+  };
+  const int ca2 = a.Ca * 2;
+  auto plan_piece = [&](const B6Unit& u, int k) -> unsigned {
+    const int hy = (int)(hyx[k] >> 8), hx = (int)(hyx[k] & 255u);
+    const int iy = u.ty0 - 2 * u.pd + hy, ix = hx - u.pd;
+    const bool ok = hyx[k] != 0xFFFFFFFFu && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    return ok ? (unsigned)(((u.n * a.H + iy) * a.W + ix) * ca2 + csl) : 0xFFFFFFFFu;
+  };
+  auto issue_xpiece = [&](unsigned off, int k, int c, int xbo) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(lds + xbo + (wave + NW * k) * 1024), 16, off, c * 64, 0, 0);
+  };
+  auto xpieces = [&](int ppt) { return (ppt + NW - 1) / NW; };
+  // ---- weight stages: [tap][NB rows][64 B]; piece pi = wave + 8 k is tap pi / PPT, rows 16 (pi % PPT) ..
+  const unsigned wloA = (unsigned)((((wave / PPTA) * a.Cm + (wave % PPTA) * 16 + prow) * a.Ca) * 2 + csl);
+  const int wkA = (NW / PPTA) * a.Cm * a.Ca * 2;
+  const unsigned wloB = (unsigned)((((wave / PPTB) * a.Cb + (wave % PPTB) * 16 + prow) * a.Cm) * 2 + csl);
+  const int wkB = (NW / PPTB) * a.Cb * a.Cm * 2;
+  auto wpieces = [&](int ntl, int ppt) { const int per = NW / ppt; return max(0, (ntl - wave / ppt + per - 1) / per); };
+  auto baseA = [&](const B6Unit& u, int c, int t0) { return (int)(((long)u.g * a.wa_stride + (long)t0 * a.Cm * a.Ca + c * 32) * 2); };
+  auto baseB = [&](const B6Unit& u, int nb, int c, int t0) {
+    return (int)(((long)u.g * a.wb_stride + ((long)t0 * a.Cb + nb * NBB) * a.Cm + c * 32) * 2);
+  };
+  // a weight stage still to be fetched: which image, its first byte, this wave's share of it
+  struct WNext { int isB, sb, np; };
+  auto issue_wpiece = [&](const WNext& w, int k, int wbo) {
+    if (w.isB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloB, w.sb + k * wkB, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rwa, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloA, w.sb + k * wkA, 0, 0);
+  };
+
+  int j = bid;
+  if (j >= total) return;
+  B6Unit cur, nu;
+  decode(j, cur);
+  nu = cur;
+  unsigned hoc[NPW], hon[NPW];
+  hyx_update(cur);
+  int jn = j + G;
+  bool has_next = jn < total;
+
+  const int XB0 = 0, HB0 = 2 * a.xb_bytes, WB0 = HB0 + NTM * a.hb_plane;
+  const int nchA = a.Ca >> 5;
+  const int nblkB = a.Cb / NBB;
+  const int wl = r * 64 + ((h << 4) ^ (((r >> 2) & 3) << 4));
+  const int tws = a.W == 32 ? 5 : 4;
+
+  // zero the intermediate image once (its padding columns are never written; re-done when the kernel size -- the image's row pitch -- changes)
+  auto zero_hb = [&]() {
+    const int n16 = (NTM * a.hb_plane) >> 4;
+    for (int i = tid; i < n16; i += 64 * NW) *reinterpret_cast<uint4*>(lds + HB0 + (i << 4)) = make_uint4(0u, 0u, 0u, 0u);
+  };
+  zero_hb();
+  int hb_ks = cur.ks;
+  // prologue: first weight stage of conv A, first x chunk
+  {
+    WNext w0{0, baseA(cur, 0, 0), wpieces(min(a.T, cur.ntaps), PPTA)};
+    for (int k = 0; k < w0.np; ++k) issue_wpiece(w0, k, WB0);
+    const int nh = xpieces(cur.ppt);
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      hoc[k] = plan_piece(cur, k);
+      hon[k] = 0xFFFFFFFFu;
+      if (k < nh) issue_xpiece(hoc[k], k, 0, XB0);
+    }
+  }
+  int par = 0, sp = 0;
+
+  // ---- one weight stage of MFMAs: MB pixel blocks x NT 32-channel blocks, operands from the pixel image at `bufpx` and the stage buffer `wbuf`
+  auto mma_stage = [&](auto MBt, auto NTt, f32x16 (&acc)[2][2], const int (&P0)[2], int bufpx, int HWp, int ks, int& ky, int& kx,
+                       const unsigned char* wbuf, int ntl, auto&& side) {
+    constexpr int MB = decltype(MBt)::value, NT = decltype(NTt)::value, NB = 32 * NT;
+    bf16x8 fxa[2][MB], fwa[2][NT], fxb[2][MB], fwb[2][NT];
+    auto load_tap = [&](bf16x8 (&fx)[2][MB], bf16x8 (&fw)[2][NT], int tl) {
+      const int toff = ky * HWp + kx + bufpx;
+      const unsigned char* wt = wbuf + tl * NB * 64;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const int px = P0[m] + toff;
+        const int ad = (px << 6) + (((px << 2) & 0x30) ^ (h << 4));
+        fx[0][m] = *reinterpret_cast<const bf16x8*>(lds + ad);
+        fx[1][m] = *reinterpret_cast<const bf16x8*>(lds + (ad ^ 32));
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        fw[0][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + wl);
+        fw[1][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ 32));
+      }
+      if (++kx == ks) { kx = 0; ++ky; }
+    };
+    auto step = [&](bf16x8 (&fx)[2][MB], bf16x8 (&fw)[2][NT], bf16x8 (&gx)[2][MB], bf16x8 (&gw)[2][NT], int tl) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_tap(gx, gw, min(tl + 1, ntl - 1));
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+            acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s2][b], fx[s2][m], acc[m][b], 0, 0, 0);
+      constexpr int NM = 2 * MB * NT, NR = 2 * (MB + NT);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < NR - NM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) side(SPT * tl + q);
+    };
+    load_tap(fxa, fwa, 0);
+#pragma unroll
+    for (int tl = 0; tl < C6_MAXT; ++tl) {
+      if (tl < ntl) {
+        if (tl & 1) step(fxb, fwb, fxa, fwa, tl); else step(fxa, fwa, fxb, fwb, tl);
+      } else {
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) side(SPT * tl + q);
+      }
+    }
+    if (kx == 0) { kx = ks - 1; --ky; } else --kx;             // undo the cursor's run-ahead
+  };
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  while (true) {
+    if (cur.ks != hb_ks) {                                      // (wave-uniform; every wave is past its reads of the old image: the previous unit ended on a barrier)
+      __syncthreads();
+      zero_hb();
+      hb_ks = cur.ks;
+    }
+    // =========================================== conv A over the (HM x W) region the second conv needs ===========================================
+    // this wave's blocks: wave and wave + 8 (32 pixels each; rows of 32, or pairs of rows of 16)
+    const int nvA = (wave + NW < cur.nblkA) ? 2 : 1;
+    int P0A[2], mrA[2], mcA[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int blk = min(wave + NW * m, cur.nblkA - 1);
+      const int q = blk * 32 + r;
+      mrA[m] = q >> tws; mcA[m] = q & (a.W - 1);
+      P0A[m] = mrA[m] * cur.WXp + mcA[m];
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[m][b] = (f32x16)(0.f);
+
+    for (int c = 0; c < nchA; ++c) {
+      const bool last_chunk = c == nchA - 1;
+      int hmode = 0, nh = 0;
+      if (!last_chunk) { hmode = 1; nh = xpieces(cur.ppt); }
+      else if (has_next) {
+        decode(jn, nu);
+        hyx_update(nu);
+        hmode = 2; nh = xpieces(nu.ppt);
+      }
+      const int xbn = XB0 + (par ^ 1) * a.xb_bytes;
+      int ky = 0, kx = 0;
+      for (int tg = 0; tg < cur.ntg; ++tg) {
+        const int t0 = tg * a.T;
+        const int ntl = min(a.T, cur.ntaps - t0);
+        __syncthreads();
+        const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
+        WNext wn{0, 0, 0};
+        if (tg + 1 < cur.ntg) wn = WNext{0, baseA(cur, c, t0 + a.T), wpieces(min(a.T, cur.ntaps - t0 - a.T), PPTA)};
+        else if (!last_chunk) wn = WNext{0, baseA(cur, c + 1, 0), wpieces(min(a.T, cur.ntaps), PPTA)};
+        else wn = WNext{1, baseB(cur, 0, 0, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
+        const int nhs = tg == 0 ? nh : 0;
+        auto side = [&](int k) {
+          if (k < NWP && k < wn.np) issue_wpiece(wn, k, wbn);
+          if (k < NPW && k < nhs) {
+            if (hmode == 2) { hon[k] = plan_piece(nu, k); issue_xpiece(hon[k], k, 0, xbn); }
+            else issue_xpiece(hoc[k], k, c + 1, xbn);
+          }
+        };
+        const int bufpx = (XB0 + par * a.xb_bytes) >> 6;
+        const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
+        if (nvA == 2) mma_stage(I2{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
+        else mma_stage(I1{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
+        sp ^= 1;
+      }
+      par ^= 1;
+    }
+    // ---- middle op on conv A's accumulators -> intermediate image in LDS (every position of the region: activation, or 0 outside the image)
+    {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      bf16* U = (bf16*)a.u;
+      bf16* HM = (bf16*)a.hmid;
+      const int WMp = cur.WXp;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m < nvA) {
+          const int mr = mrA[m], mc = mcA[m];
+          const int iy = cur.ty0 - cur.pd + mr;
+          const bool inimg = (unsigned)iy < (unsigned)a.H;
+          const bool owned = mr >= cur.pd && mr < cur.pd + a.TH;
+          const long pix = (((long)cur.n * a.H + iy) * a.W + mc) * a.Cm;
+          const int hpx = mr * WMp + mc + cur.pd;
+          const int hsw = (hpx >> 2) & 3;
+#pragma unroll
+          for (int b = 0; b < NTM; ++b)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              float v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = a.alpha_mid * acc[m][b][8 * p + q];
+              const unsigned A0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[0], (bf16)v[1]}), A1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[2], (bf16)v[3]});
+              const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
+              const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+              const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+              // this lane: channels c0 .. c0 + 7 of pixel (mr, mc), rounded to bf16 (as the unfused conv writes them)
+              const int c0 = 32 * b + 16 * p + 8 * h;
+              const unsigned pk[4] = {s0[0], s1[0], s0[1], s1[1]};
+              unsigned ho[4] = {0u, 0u, 0u, 0u};
+              if (inimg) {
+                const long eo = pix + c0;
+                const float* ep = a.e + (long)cur.n * a.Cm + c0;
+                uint32_t r4[8];
+                if (a.p > 0.f) {
+                  const long q0 = eo >> 2;
+                  philox((uint32_t)q0, (uint32_t)(q0 >> 32), seed_lo, seed_hi, r4);
+                  philox((uint32_t)(q0 + 1), (uint32_t)((q0 + 1) >> 32), seed_lo, seed_hi, r4 + 4);
+                }
+                if (a.mode == 0) {
+                  if (owned) *reinterpret_cast<uint4*>(U + eo) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#pragma unroll
+                  for (int j2 = 0; j2 < 4; ++j2) {
+                    const bf2 yv = __builtin_bit_cast(bf2, pk[j2]);
+                    float f0 = mp_silu_f((float)yv[0] * ep[2 * j2]);
+                    float f1 = mp_silu_f((float)yv[1] * ep[2 * j2 + 1]);
+                    if (a.p > 0.f) {
+                      f0 = u01(r4[2 * j2]) >= a.p ? f0 * drop_inv : 0.f;
+                      f1 = u01(r4[2 * j2 + 1]) >= a.p ? f1 * drop_inv : 0.f;
+                    }
+                    ho[j2] = __builtin_bit_cast(unsigned, (bf2){(bf16)f0, (bf16)f1});
+                  }
+                  if (owned) *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+                } else {
+                  // FiLM / mp_silu / dropout backward on the bf16-rounded d(activation): du = g * silu'(u e) * e, de += g * silu'(u e) * u
+                  const uint4 uq = *reinterpret_cast<const uint4*>(U + eo);
+                  const unsigned uk[4] = {uq.x, uq.y, uq.z, uq.w};
+                  float dsum[8];
+#pragma unroll
+                  for (int j2 = 0; j2 < 4; ++j2) {
+                    const bf2 gv = __builtin_bit_cast(bf2, pk[j2]);
+                    const bf2 uv = __builtin_bit_cast(bf2, uk[j2]);
+                    float g0 = (float)gv[0], g1 = (float)gv[1];
+                    if (a.p > 0.f) {
+                      g0 = u01(r4[2 * j2]) >= a.p ? g0 * drop_inv : 0.f;
+                      g1 = u01(r4[2 * j2 + 1]) >= a.p ? g1 * drop_inv : 0.f;
+                    }
+                    const float u0 = (float)uv[0], u1 = (float)uv[1];
+                    g0 *= mp_silu_grad_f(u0 * ep[2 * j2]); g1 *= mp_silu_grad_f(u1 * ep[2 * j2 + 1]);
+                    dsum[2 * j2] = g0 * u0; dsum[2 * j2 + 1] = g1 * u1;
+                    g0 *= ep[2 * j2]; g1 *= ep[2 * j2 + 1];
+                    ho[j2] = __builtin_bit_cast(unsigned, (bf2){(bf16)g0, (bf16)g1});
+                  }
+                  if (owned) {
+                    *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+                    if (a.de) {
+                      // the 32 lanes of a half-wave hold the same 8 channels of 32 different pixels
+#pragma unroll
+                      for (int q = 0; q < 8; ++q) {
+                        float s = dsum[q];
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                        if (r == 0) atomicAdd(a.de + (long)cur.n * a.Cm + c0 + q, s);
+                      }
+                    }
+                  }
+                }
+              }
+              *reinterpret_cast<uint4*>(lds + HB0 + b * a.hb_plane + (hpx << 6) + ((((16 * p + 8 * h) >> 3) ^ hsw) << 4)) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+            }
+        }
+      }
+    }
+    // =========================================== conv B over the tile, intermediate read from LDS ===========================================
+    {
+      const int q = wave * 32 + r;
+      const int orow = q >> tws, oc = q & (a.W - 1);
+      const int P0B[2] = {orow * cur.WXp + oc, 0};
+      const int yy = cur.ty0 + orow;
+      for (int nb = 0; nb < nblkB; ++nb) {
+        f32x16 accb[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) accb[0][b] = (f32x16)(0.f);
+        for (int c = 0; c < NTM; ++c) {
+          int ky = 0, kx = 0;
+          for (int tg = 0; tg < cur.ntg; ++tg) {
+            const int t0 = tg * a.T;
+            const int ntl = min(a.T, cur.ntaps - t0);
+            __syncthreads();
+            const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
+            WNext wn{0, 0, 0};
+            if (tg + 1 < cur.ntg) wn = WNext{1, baseB(cur, nb, c, t0 + a.T), wpieces(min(a.T, cur.ntaps - t0 - a.T), PPTB)};
+            else if (c + 1 < NTM) wn = WNext{1, baseB(cur, nb, c + 1, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
+            else if (nb + 1 < nblkB) wn = WNext{1, baseB(cur, nb + 1, 0, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
+            else if (has_next) wn = WNext{0, baseA(nu, 0, 0), wpieces(min(a.T, nu.ntaps), PPTA)};
+            auto side = [&](int k) { if (k < NWP && k < wn.np) issue_wpiece(wn, k, wbn); };
+            const int bufpx = (HB0 + c * a.hb_plane) >> 6;
+            const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
+            mma_stage(I1{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
+            sp ^= 1;
+          }
+        }
+        // epilogue: y = alpha * acc + beta * res (fp32, one rounding), 16-byte stores
+        bf16* Y = (bf16*)a.y;
+        const bf16* R = (const bf16*)a.res;
+        const long pix = (((long)cur.n * a.H + yy) * a.W + oc) * a.Cb + nb * NBB;
+#pragma unroll
+        for (int b = 0; b < NTB; ++b)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) v[q2] = a.alpha * accb[0][b][8 * p + q2];
+            if (R) {
+              const long o0 = pix + 32 * b + 16 * p + 4 * h;
+              const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);
+              const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+#pragma unroll
+              for (int q2 = 0; q2 < 4; ++q2) { v[q2] += a.beta * (float)r0[q2]; v[4 + q2] += a.beta * (float)r1[q2]; }
+            }
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const unsigned A0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[0], (bf16)v[1]}), A1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[2], (bf16)v[3]});
+            const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+            *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+      }
+    }
+    if (!has_next) break;
+    cur = nu;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) hoc[k] = hon[k];
+    jn += G;
+    has_next = jn < total;
+  }
+#endif
+}
+
+}  // namespace

@@ -16,7 +16,9 @@ struct __attribute__((aligned(8))) OptDesc {   // mirrored by hdmoe_hip/optim.py
 };
 constexpr int OPT_CHUNK = 4096;
 
-__global__ __launch_bounds__(256) void mt_sumsq_kernel(float* out, const OptDesc* descs, const int2* chunks) {
+// Two deterministic passes (no float atomics): the clip coefficient multiplies every update, so a run-to-run difference in the last bit of
+// the norm would let data-parallel replicas drift apart bit by bit.
+__global__ __launch_bounds__(256) void mt_sumsq_kernel(float* partial, const OptDesc* descs, const int2* chunks) {
   __shared__ float sm[16];
   const int2 c = chunks[blockIdx.x];
   const OptDesc d = descs[c.x];
@@ -26,7 +28,14 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(float* out, const OptDesc
   float acc = 0.f;
   for (long i = i0 + threadIdx.x; i < i1; i += 256) { const float v = g[i]; acc += v * v; }
   acc = block_sum(acc, sm);
-  if (threadIdx.x == 0) atomicAdd(out, acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(1024) void mt_sumsq_final_kernel(float* out, const float* partial, int n) {
+  __shared__ float sm[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += partial[i];       // fixed order per thread, fixed tree below
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) out[0] = acc;
 }
 // coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_)
 DEVI float clip_coef(const float* sumsq, float max_norm) {
@@ -76,17 +85,16 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const OptDesc* descs, con
   }
 }
 
-__global__ void zero1_kernel(float* p) { p[0] = 0.f; }
-
 }  // namespace
 
 extern "C" {
 
 int hdmoe_opt_desc_bytes(void) { return (int)sizeof(OptDesc); }
-// sumsq (1 float, zeroed here) = sum over all tensors of g^2
-int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, hipStream_t stream) {
-  hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, stream, sumsq);      // (a kernel, not a memset: memset nodes of captured hipGraphs proved unreliable, see loss.hip)
-  if (nchunks > 0) hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, sumsq, (const OptDesc*)descs, (const int2*)chunks);
+// sumsq (1 float) = sum over all tensors of g^2; ws: nchunks floats of scratch
+int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, float* ws, hipStream_t stream) {
+  if (!sumsq || (nchunks > 0 && !ws)) return HDMOE_EINVAL;
+  if (nchunks > 0) hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, ws, (const OptDesc*)descs, (const int2*)chunks);
+  hipLaunchKernelGGL(mt_sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, sumsq, ws, nchunks > 0 ? nchunks : 0);
   return hdmoe_launch_status();
 }
 int hdmoe_mt_clip_scale(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, hipStream_t stream) {

@@ -411,10 +411,12 @@ class _MPConvFn(torch.autograd.Function):
         ctx.wd = wd
         ctx.ent = ent
         ctx.bank = _bank.ACTIVE if ent is not None else None
-        y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
+        global _PRECOMP
+        pre, _PRECOMP = _PRECOMP, None
+        y = pre if pre is not None else torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
         req = _FILM_REQ
-        fused_film = False
-        if (req is not None and ent is not None and not split and res is None and not ones and x.dtype == torch.bfloat16 and PROFILE is None
+        fused_film = pre is not None                          # (output already computed by the fused block kernel, ops.unet_block_fused)
+        if (pre is None and req is not None and ent is not None and not split and res is None and not ones and x.dtype == torch.bfloat16 and PROFILE is None
                 and Ho == H and Wo == W and Cphys == I):
             # FiLM + mp_silu + dropout as a second output of this conv's epilogue (ops.mp_conv_film): one launch less on the branch's chain
             hbuf = torch.empty_like(y)
@@ -527,6 +529,7 @@ class _MPConvFn(torch.autograd.Function):
         return (dx, dres, None, None, *dws, *dgs)
 
 
+_PRECOMP = None                           # output tensor a fused launch has already produced for the NEXT _MPConvFn.forward (ops.unet_block_fused)
 F32S = 2                                  # C-ABI dtype code: fp32 tensors, split-bf16 arithmetic (include/hdmoe.h HDMOE_F32S)
 # The fp32 router trunks run on the bf16 matrix pipe as split-bf16 (3 MFMAs per product, ~1e-5 relative): HDMOE_ROUTER_SPLIT=0
 # keeps them on the fp32-input MFMA kernels.
@@ -982,6 +985,53 @@ def mp_conv_film(x: Tensor, weights, gain, emb: Tensor, p: float, training: bool
     if req.h is not None:
         return _FilmDoneFn.apply(y, req.emb, p, req.seed, req.h)
     return _FilmSiluFn.apply(y, req.emb, p, req.seed)
+
+
+BLK6 = _os.environ.get("HDMOE_BLK6", "1") != "0"
+
+
+def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, gain2: float, emb: Tensor, p: float, training: bool,
+                     seg: Optional[Tensor], alpha: float, beta: float, res_grad_raw: bool = False) -> Optional[Tensor]:
+    """Main branch of Unet_block (reference model_components.py:240-253) for a bank of experts as ONE launch (csrc/blk6.hip):
+    alpha * conv_res2(dropout(mp_silu(conv_res1(h) * emb))) + beta * res, the activation tile kept in LDS between the two convs.
+    Returns None when the fused kernel does not apply (no ready weight-bank entries, fp32 mode, shapes outside its domain): the caller
+    then runs the layers one by one.  The autograd graph is the unfused one (conv -> FiLM -> conv nodes over the tensors the fused
+    launch wrote), so the backward is unchanged."""
+    global _PRECOMP
+    w1s, w2s = list(w1s), list(w2s)
+    if not (BLK6 and _bank.ACTIVE is not None and PROFILE is None and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_cuda):
+        return None
+    if res is not None and (res.dtype != h.dtype or not res.is_contiguous()):
+        return None
+    ent1 = _bank.ACTIVE.lookup(w1s, h.dtype, float(gain1), 1.0, True)
+    ent2 = _bank.ACTIVE.lookup(w2s, h.dtype, float(gain2), float(alpha), True)
+    if ent1 is None or ent2 is None or ent1.khs != ent1.kws or ent1.khs != ent2.khs or ent2.khs != ent2.kws:
+        return None
+    h = _c(h)
+    N, H, W, Cin = h.shape
+    C = ent1.O
+    if ent1.I != Cin or ent2.I != C or ent2.O != C or (seg is None and len(w1s) != 1):
+        return None
+    p = float(p) if training else 0.0
+    e32 = _f32(emb)
+    seed = _next_seed() if p > 0.0 else 0
+    u = torch.empty((N, H, W, C), dtype=h.dtype, device=h.device)
+    hb = torch.empty_like(u)
+    y = torch.empty_like(u)
+    if call("hdmoe_unet_block_fwd", h, ent1.wf, ent2.wf, u, hb, y, res, e32, seed, step_counter(h.device), p, float(alpha), float(beta), seg,
+            len(w1s), ent1.wstride, ent2.wstride, N, H, W, Cin, C, ent1.khs, _dt(h)) != 0:
+        return None
+    STATS["blk"] += 1
+    ws1 = w1s if seg is not None else w1s[0]
+    ws2 = w2s if seg is not None else w2s[0]
+    try:
+        _PRECOMP = u
+        uu = mp_conv(h, ws1, gain1, seg=seg, training=training)
+        hh = _FilmDoneFn.apply(uu, e32, p, seed, hb)
+        _PRECOMP = y
+        return mp_conv(hh, ws2, gain2, seg=seg, res=res, alpha=alpha, beta=beta, training=training, res_grad_raw=res_grad_raw)
+    finally:
+        _PRECOMP = None
 
 
 def film_silu(u: Tensor, e: Tensor, p: float = 0.0, training: bool = False) -> Tensor:

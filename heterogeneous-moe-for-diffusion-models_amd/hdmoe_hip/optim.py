@@ -46,6 +46,7 @@ class _Table:
         self.chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
         self.n = len(chunks)
         self.ntensors = len(entries)
+        self.ws = torch.empty(max(self.n, 1), dtype=torch.float32, device=dev)          # per-chunk partial sums of the deterministic norm
         self.sig = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _, _ in entries) + tuple(uses or ())
 
 
@@ -75,7 +76,7 @@ def grad_norm_sq(params: Iterable[torch.nn.Parameter], key=None) -> Tuple[torch.
         tab = _Table(ents)
         if key is not None:
             _norm_tables[key] = tab
-    call("hdmoe_mt_sumsq", out, tab.descs, tab.chunks, tab.n)
+    call("hdmoe_mt_sumsq", out, tab.descs, tab.chunks, tab.n, tab.ws)
     return out, tab
 
 

@@ -149,13 +149,20 @@ def unet_block_bank_forward(blocks: Sequence["Unet_block"], x: Tensor, embedding
         skip_next = b0.conv_skip is not None
         x, h = ops.silu_branch(x, gx_scale=1.0 if skip_next else beta)     # main branch + skip / residual: one fused backward pass
         raw = not skip_next
-    # conv_res1 -> FiLM * emb -> mp_silu -> F.dropout: in the bf16 bank path the three elementwise steps are a second output of the conv's epilogue
-    y = ops.mp_conv_film(h, [b.conv_res1.weights for b in blocks], b0.conv_gain1, emb, b0.dropout, tr, seg=seg)
+    w1, w2 = [b.conv_res1.weights for b in blocks], [b.conv_res2.weights for b in blocks]
     if b0.type == "dec" and b0.conv_skip is not None:
         x = conv("conv_skip", x, alpha=beta)                   # beta folded into the skip projection's weight image
-        return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=1.0)
+        rbeta, raw = 1.0, False
+    else:
+        rbeta = beta
+    # bf16 bank path: conv_res1 -> FiLM * emb -> mp_silu -> F.dropout -> conv_res2 -> mp_sum as ONE launch, the activation tile kept in LDS (csrc/blk6.hip)
+    yb = ops.unet_block_fused(h, x, w1, w2, b0.conv_gain1, b0.conv_gain2, emb, b0.dropout, tr, seg, alpha=t / n, beta=rbeta, res_grad_raw=raw)
+    if yb is not None:
+        return yb
+    # conv_res1 -> FiLM * emb -> mp_silu -> F.dropout: the three elementwise steps as a second output of the conv's epilogue (eval), or one pass
+    y = ops.mp_conv_film(h, w1, b0.conv_gain1, emb, b0.dropout, tr, seg=seg)
     # conv_res2 with mp_sum(x, main, residual_balance) fused into its epilogue
-    return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=beta, res_grad_raw=raw)
+    return conv("conv_res2", y, b0.conv_gain2, res=x, alpha=t / n, beta=rbeta, res_grad_raw=raw)
 
 
 class Unet_block(nn.Module):

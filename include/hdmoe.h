@@ -286,6 +286,23 @@ int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU
                        const float* sse, const float* denoised, const float* target, const float* log_var, const float* rU,
                        const float* rV, int B, long L, int E, float unet_bal, float vit_bal, float z_bal, HS stream);
 
+/* ---- K3+K4 fused: Unet_block main branch as one persistent launch (csrc/blk6.hip; reference models/model_components.py:240-253) ----
+ * forward:  u = conv(x, w1); h = dropout_p(mp_silu(u * e[n][c])); y = alpha * conv(h, w2) + beta * res   (u, h, y written; the
+ *           activation tile stays in LDS between the two convs).  x [N][H][W][Cin], u / h / y / res [N][H][W][C] bf16, e fp32 [N][C];
+ *           w1 [g][tap][C][Cin], w2 [g][tap][C][C] forward weight images; kh: per-expert square kernel size, "same" padding.
+ * backward: dh = alpha_mid * dgrad(dy, wd2) (stays in LDS); du = dropout / mp_silu / FiLM backward (written); de [N][C] += ...;
+ *           dx = alpha * dgrad(du, wd1).  wd2 [g][tap][C][C], wd1 [g][tap][Cin][C] flipped dgrad images; u from the forward.
+ * Both return 1 without launching outside the kernel's domain (bf16, W in {16, 32}, H % (256 / W) == 0, k in {3, 5, 7},
+ * Cin % 32 == 0, C in {32, 64}). */
+int hdmoe_unet_block_fwd(const void* x, const void* w1, const void* w2, void* u, void* h, void* y, const void* res, const float* e,
+                         unsigned long long seed, const unsigned long long* seed_dev, float p, float alpha, float beta, const int* seg,
+                         int ngroups, long w1stride, long w2stride, int N, int H, int W, int Cin, int C, const int* kh, int dtype,
+                         HS stream);
+int hdmoe_unet_block_bwd(const void* dy, const void* wd2, const void* wd1, const void* u, void* du, void* dx, float* de, const float* e,
+                         unsigned long long seed, const unsigned long long* seed_dev, float p, float alpha, float alpha_mid, const int* seg,
+                         int ngroups, long wd2stride, long wd1stride, int N, int H, int W, int Cin, int C, const int* kh, int dtype,
+                         HS stream);
+
 /* ---- N3: fused multi-tensor clip_grad_norm_ + AdamW  (Utils/training.py:55-65,195-197) ----------------------------------- */
 /* descs: device array of {p, g, m, v, step, use addresses, numel, group} (hdmoe_opt_desc_bytes() bytes each); chunks: device int32 pairs
  * (descriptor index, 4096-element chunk index).  The clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) is read on the device.
@@ -293,7 +310,7 @@ int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU
  * gradient this step, or 0 = always -- a tensor of an expert that got no sample is skipped like a grad-None tensor in torch.optim.AdamW
  * (reference models/model_config1.py:26-29 leaves such an expert out of the graph; Utils/training.py:195-197). */
 int hdmoe_opt_desc_bytes(void);
-int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, HS stream);
+int hdmoe_mt_sumsq(float* sumsq, const void* descs, const int* chunks, int nchunks, float* ws, HS stream);   /* ws: nchunks floats; deterministic */
 int hdmoe_mt_clip_scale(const void* descs, const int* chunks, int nchunks, const float* sumsq, float max_norm, HS stream);
 int hdmoe_mt_adamw(const void* descs, const int* chunks, int nchunks, int ntensors, const float* sumsq, float max_norm, const float* group_lr,
                    const float* group_wd, int ngroups, float beta1, float beta2, float eps, HS stream);

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", bf16=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +40,8 @@ def _worker(rank, world, port, q, backend="gloo"):
     from oracle.recipe import fill_state, make_inputs
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    hdmoe_hip.set_compute_dtype(torch.float32)
+    hdmoe_hip.set_compute_dtype(torch.bfloat16 if bf16 else torch.float32)
+    tol = 2e-2 if bf16 else 3e-4               # bf16: the reference side accumulates two batches through one replica (other bf16 roundings)
     kw = configs.model_kwargs(**configs.BASELINE_CONFIGS[2]["over"])
     crit = EDM_LOSS(num_experts=4, sigma_data=0.5, Unet_bal=0.05, vit_bal=0.1, z_bal=0.005, prior_bal=0.0)
 
@@ -92,20 +93,21 @@ def _worker(rank, world, port, q, backend="gloo"):
         if n in acc:
             scale = float(acc[n].abs().max())
             err = float((p.grad - acc[n]).abs().max())
-            if err > 3e-4 * scale + 1e-7:
+            if err > tol * scale + 1e-7:
                 bad.append((n, err, scale))
     q.put((rank, bad[:5], len(acc)))
     dist.destroy_process_group()
 
 
-def test_staged_step_with_bucket_overlap_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_staged_step_with_bucket_overlap_two_ranks_on_one_gpu(bf16):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "gloo", bf16)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
