@@ -27,12 +27,14 @@
 
 namespace {
 
-template <int NTM, int NTB>
+template <int NTM, int NTB, int MODE>
 __global__ __launch_bounds__(64 * C6_NW) void blk6_kernel(B6Args a) {
-  blk6_body<NTM, NTB>(a, blockIdx.x, gridDim.x);
+  blk6_body<NTM, NTB, MODE>(a, blockIdx.x, gridDim.x);
 }
 
 struct B6Plan { B6Args a; int NTM, NTB; unsigned G; size_t lds; };
+void* g_b6_stamps = nullptr;
+constexpr int B6_EB = 256;                    // bytes of LDS behind the weight buffers: the unit's FiLM vector (<= 64 floats)
 
 int blk6_plan(const void* x, const void* wa, const void* wb, void* y, const void* res, const int* seg, int ngroups, long wa_stride,
               long wb_stride, int N, int H, int W, int Ca, int Cm, int Cb, const int* ks, B6Plan& plan) {
@@ -66,33 +68,37 @@ int blk6_plan(const void* x, const void* wa, const void* wb, void* y, const void
   const int nbmax = 32 * (NTM > NTB ? NTM : NTB);
   int best = 0, best_stages = 1 << 30;
   for (int t = 9; t >= 2; --t) {
-    if (t * (nbmax / 16) > 40 || 2 * a.xb_bytes + NTM * a.hb_plane + 2 * t * nbmax * 64 > 160 * 1024) continue;
+    if (t * (nbmax / 16) > 40 || 2 * a.xb_bytes + NTM * a.hb_plane + 2 * t * nbmax * 64 + B6_EB > 160 * 1024) continue;
     int stages = 0;
     for (int g = 0; g < ngroups; ++g) stages += (ks[g] * ks[g] + t - 1) / t;
     if (stages <= best_stages) { best_stages = stages; best = t; }
   }
   static const int force_t = getenv("HDMOE_B6_T") ? atoi(getenv("HDMOE_B6_T")) : 0;
-  if (force_t && force_t >= 2 && force_t <= 9 && force_t * (nbmax / 16) <= 40 && 2 * a.xb_bytes + NTM * a.hb_plane + 2 * force_t * nbmax * 64 <= 160 * 1024) best = force_t;
+  if (force_t && force_t >= 2 && force_t <= 9 && force_t * (nbmax / 16) <= 40 && 2 * a.xb_bytes + NTM * a.hb_plane + 2 * force_t * nbmax * 64 + B6_EB <= 160 * 1024) best = force_t;
   if (!best) return 1;
   a.T = best; a.wb_bytes = best * nbmax * 64;
   auto recip = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)d + 1); };
   a.m_tpi = recip(a.tpi); a.m_T = recip(a.T);
-  plan.lds = 2 * (size_t)a.xb_bytes + (size_t)NTM * a.hb_plane + 2 * (size_t)a.wb_bytes;
+  plan.lds = 2 * (size_t)a.xb_bytes + (size_t)NTM * a.hb_plane + 2 * (size_t)a.wb_bytes + B6_EB;
   const long units = (long)N * a.tpi;
   static const int gcap = getenv("HDMOE_B6_G") ? atoi(getenv("HDMOE_B6_G")) : 256;
   plan.G = (unsigned)(units < gcap ? units : gcap);
   plan.NTM = NTM; plan.NTB = NTB;
+  a.stamps = (unsigned long long*)g_b6_stamps;
+  static const int dbg = getenv("HDMOE_B6_DBG") ? atoi(getenv("HDMOE_B6_DBG")) : 0;
+  a.dbg = dbg;
   return 0;
 }
 
+template <int MODE>
 int blk6_launch(const B6Plan& plan, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     attr_set = true;
-#define B6_ATTR(M, B) (void)hipFuncSetAttribute((const void*)blk6_kernel<M, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define B6_ATTR(M, B) (void)hipFuncSetAttribute((const void*)blk6_kernel<M, B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     B6_ATTR(1, 1); B6_ATTR(1, 2); B6_ATTR(2, 1); B6_ATTR(2, 2);
   }
-#define B6_LAUNCH(M, B) hipLaunchKernelGGL((blk6_kernel<M, B>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.a)
+#define B6_LAUNCH(M, B) hipLaunchKernelGGL((blk6_kernel<M, B, MODE>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.a)
   if (plan.NTM == 2) { if (plan.NTB == 2) B6_LAUNCH(2, 2); else B6_LAUNCH(2, 1); }
   else { if (plan.NTB == 2) B6_LAUNCH(1, 2); else B6_LAUNCH(1, 1); }
   return hdmoe_launch_status();
@@ -101,6 +107,9 @@ int blk6_launch(const B6Plan& plan, hipStream_t stream) {
 }  // namespace
 
 extern "C" {
+
+// development hook (tools/blk6_bench.py --stamps): 8 x 64 u64 device buffer receiving workgroup 0's in-kernel time stamps
+int hdmoe_blk6_debug_stamps(void* buf) { g_b6_stamps = buf; return HDMOE_OK; }
 
 /* Forward of Unet_block's main branch for all experts of a layer (reference models/model_components.py:240-253):
  *   u = conv(x, w1)                         [N][H][W][C]   (written: the backward needs the pre-activation)
@@ -123,7 +132,7 @@ int hdmoe_unet_block_fwd(const void* x, const void* w1, const void* w2, void* u,
   B6Args& a = plan.a;
   a.alpha = alpha; a.beta = beta; a.alpha_mid = 1.f; a.mode = 0; a.e = e; a.u = u; a.hmid = h; a.de = nullptr;
   a.seed_dev = seed_dev; a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.p = p;
-  return blk6_launch(plan, stream);
+  return blk6_launch<0>(plan, stream);
 }
 
 /* Input-gradient chain of the same branch:
@@ -144,7 +153,7 @@ int hdmoe_unet_block_bwd(const void* dy, const void* wd2, const void* wd1, const
   B6Args& a = plan.a;
   a.alpha = alpha; a.beta = 0.f; a.alpha_mid = alpha_mid; a.mode = 1; a.e = e; a.u = const_cast<void*>(u); a.hmid = du; a.de = de;
   a.seed_dev = seed_dev; a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.p = p;
-  return blk6_launch(plan, stream);
+  return blk6_launch<1>(plan, stream);
 }
 
 }  // extern "C"

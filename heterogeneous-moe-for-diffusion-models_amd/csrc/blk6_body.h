@@ -32,11 +32,14 @@ struct B6Args {
   void* hmid;                         // [N][H][W][Cm]: mode 0 OUT the activation (input of conv B, saved for its weight gradient); mode 1 OUT du
   float* de;                          // mode 1: [N][Cm] += sum over pixels of d(mid)/d(e)
   const unsigned long long* seed_dev; unsigned seed_lo, seed_hi; float p;
+  unsigned long long* stamps;         // development: s_memtime stamps of workgroup 0 ([wave][64] slots), or null
+  int dbg;                            // development ablations: 1 no MFMA loops, 2 no DMA inside the loops, 4 no global stores, 8 no middle op
 };
 
-struct B6Unit { int g, ks, pd, ntaps, ntg, WXp, HX, HM, ppt, nblkA, n, ty0; };
+struct B6Unit { int g, ks, n, ty0, rend; };     // (everything else follows from ks: kept out of the record, scalar registers are scarce here)
+struct B6Geo { int pd, ntaps, ntg, WXp, HX, HM, ppt, nblkA; };
 
-template <int NTM, int NTB>
+template <int NTM, int NTB, int MODE>
 DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int NW = 8;
@@ -44,7 +47,6 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   constexpr int PPTA = NBM / 16, PPTB = NBB / 16;
   constexpr int NPW = 6;                        // x pieces per wave (<= 48 pieces of 16 pixels per chunk)
   constexpr int NWP = 5;                        // weight pieces per wave per stage (T * NB / 16 <= 40)
-  constexpr int SPT = 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,6 +61,14 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   if (a.p > 0.f) mix_seed(seed_lo, seed_hi, a.seed_dev);
   const float drop_inv = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
 
+  int nstamp = 0;
+  auto stamp = [&](int tag) {
+    if (a.stamps && bid == 0 && lane == 0 && nstamp < 63) {
+      a.stamps[wave * 64 + nstamp] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull);
+      ++nstamp;
+    }
+  };
+  stamp(1);
   // ---- unit list (as conv6_body.h): groups in descending kernel size; a unit = one TH x W tile of one routed row
   const int oi_l = lane & 7;
   int v_g = 0, v_ks = 0;
@@ -89,14 +99,20 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
     const int slot = (int)__builtin_ctzll(hit | (1ull << 7));
     const int uu = j - __builtin_amdgcn_readlane(v_ustart, slot);
     const int row0 = __builtin_amdgcn_readlane(v_row0, slot);
+    u.rend = row0 + __builtin_amdgcn_readlane(v_rows, slot);
     u.g = __builtin_amdgcn_readlane(v_g, slot); u.ks = __builtin_amdgcn_readlane(v_ks, slot);
-    u.pd = (u.ks - 1) >> 1; u.ntaps = u.ks * u.ks; u.ntg = udiv(u.ntaps + a.T - 1, a.m_T, a.T);
-    u.WXp = a.W + u.ks - 1; u.HX = a.TH + 2 * (u.ks - 1); u.HM = a.TH + u.ks - 1;
-    u.ppt = (u.WXp * u.HX + 15) >> 4;
-    u.nblkA = (u.HM * a.W) >> 5;
     const int img = udiv(uu, a.m_tpi, a.tpi);
     u.n = row0 + img; u.ty0 = (uu - img * a.tpi) * a.TH;
   };
+  auto geo_of = [&](int ks) {
+    B6Geo q;
+    q.pd = (ks - 1) >> 1; q.ntaps = ks * ks; q.ntg = udiv(q.ntaps + a.T - 1, a.m_T, a.T);
+    q.WXp = a.W + ks - 1; q.HX = a.TH + 2 * (ks - 1); q.HM = a.TH + ks - 1;
+    q.ppt = (q.WXp * q.HX + 15) >> 4;
+    q.nblkA = (q.HM * a.W) >> 5;
+    return q;
+  };
+  auto ppt_of = [&](int ks) { return ((a.W + ks - 1) * (a.TH + 2 * (ks - 1)) + 15) >> 4; };
 
   // ---- x pieces (16 pixels x 32 channels of one chunk) of the unit's (HX x WXp) input region; ~0 = padding (the DMA writes zeros)
   unsigned hyx[NPW];
@@ -104,22 +120,24 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   auto hyx_update = [&](const B6Unit& u) {
     if (u.ks == hyx_ks) return;
     hyx_ks = u.ks;
-    const int magic = (1 << 20) / u.WXp + 1;
-    const int npx = u.WXp * u.HX;
+    const int WXp = a.W + u.ks - 1, HX = a.TH + 2 * (u.ks - 1), ppt = (WXp * HX + 15) >> 4;
+    const int magic = (1 << 20) / WXp + 1;
+    const int npx = WXp * HX;
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       const int pi = wave + NW * k;
       const int px = 16 * pi + prow;
       int hy = (int)(((unsigned)px * (unsigned)magic) >> 20);
-      if (hy * u.WXp > px) --hy;
-      const int hx = px - hy * u.WXp;
-      hyx[k] = (pi < u.ppt && px < npx) ? (unsigned)((hy << 8) | hx) : 0xFFFFFFFFu;
+      if (hy * WXp > px) --hy;
+      const int hx = px - hy * WXp;
+      hyx[k] = (pi < ppt && px < npx) ? (unsigned)((hy << 8) | hx) : 0xFFFFFFFFu;
     }
   };
   const int ca2 = a.Ca * 2;
   auto plan_piece = [&](const B6Unit& u, int k) -> unsigned {
     const int hy = (int)(hyx[k] >> 8), hx = (int)(hyx[k] & 255u);
-    const int iy = u.ty0 - 2 * u.pd + hy, ix = hx - u.pd;
+    const int pd = (u.ks - 1) >> 1;
+    const int iy = u.ty0 - 2 * pd + hy, ix = hx - pd;
     const bool ok = hyx[k] != 0xFFFFFFFFu && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     return ok ? (unsigned)(((u.n * a.H + iy) * a.W + ix) * ca2 + csl) : 0xFFFFFFFFu;
   };
@@ -139,11 +157,30 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   };
   // a weight stage still to be fetched: which image, its first byte, this wave's share of it
   struct WNext { int isB, sb, np; };
-  auto issue_wpiece = [&](const WNext& w, int k, int wbo) {
-    if (w.isB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloB, w.sb + k * wkB, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rwa, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloA, w.sb + k * wkA, 0, 0);
+  auto issue_wstage = [&](const WNext& w, int wbo) {            // this wave's pieces of one stage, back to back
+    if (a.dbg & 2) return;
+    if (w.isB) {
+#pragma unroll
+      for (int k = 0; k < NWP; ++k)
+        if (k < w.np) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloB, w.sb + k * wkB, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NWP; ++k)
+        if (k < w.np) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwa, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wloA, w.sb + k * wkA, 0, 0);
+    }
   };
 
+  // Every LDS-DMA piece is written by ONE wave and read by all of them after the next barrier.  The compiler orders a wave's own LDS reads
+  // behind its own DMA, but puts no vmcnt wait in front of a barrier whose successor code has none of them (seen in the ISA of the conv B
+  // loop: `s_waitcnt lgkmcnt(0); s_barrier`; with 2-tap stages the pieces then land after another wave has read them): wait explicitly.
+  // vm = false: the first stage behind an epilogue.  Its DMA pieces were issued before the epilogue and every wave waited for its own
+  // (drain_dma) before issuing the epilogue's global stores, so the barrier must not wait for those stores (vmcnt counts them too, in order).
+  // (a raw s_barrier: __syncthreads() carries a workgroup-scope release fence, i.e. an s_waitcnt vmcnt(0) of its own for the global stores)
+  auto stage_barrier = [&](bool vm = true) {
+    if (vm) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  auto drain_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   int j = bid;
   if (j >= total) return;
   B6Unit cur, nu;
@@ -154,7 +191,7 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   int jn = j + G;
   bool has_next = jn < total;
 
-  const int XB0 = 0, HB0 = 2 * a.xb_bytes, WB0 = HB0 + NTM * a.hb_plane;
+  const int XB0 = 0, HB0 = 2 * a.xb_bytes, WB0 = HB0 + NTM * a.hb_plane, EB0 = WB0 + 2 * a.wb_bytes;     // EB: this unit's FiLM vector e[n][0 .. Cm)
   const int nchA = a.Ca >> 5;
   const int nblkB = a.Cb / NBB;
   const int wl = r * 64 + ((h << 4) ^ (((r >> 2) & 3) << 4));
@@ -167,11 +204,12 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   };
   zero_hb();
   int hb_ks = cur.ks;
+  B6Geo cg = geo_of(cur.ks);
   // prologue: first weight stage of conv A, first x chunk
   {
-    WNext w0{0, baseA(cur, 0, 0), wpieces(min(a.T, cur.ntaps), PPTA)};
-    for (int k = 0; k < w0.np; ++k) issue_wpiece(w0, k, WB0);
-    const int nh = xpieces(cur.ppt);
+    WNext w0{0, baseA(cur, 0, 0), wpieces(min(a.T, cg.ntaps), PPTA)};
+    issue_wstage(w0, WB0);
+    const int nh = xpieces(cg.ppt);
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       hoc[k] = plan_piece(cur, k);
@@ -182,81 +220,93 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   int par = 0, sp = 0;
 
   // ---- one weight stage of MFMAs: MB pixel blocks x NT 32-channel blocks, operands from the pixel image at `bufpx` and the stage buffer `wbuf`
-  auto mma_stage = [&](auto MBt, auto NTt, f32x16 (&acc)[2][2], const int (&P0)[2], int bufpx, int HWp, int ks, int& ky, int& kx,
-                       const unsigned char* wbuf, int ntl, auto&& side) {
+  // (the tap cursor goes in and out BY VALUE, packed ky << 8 | kx: as reference parameters of this generic lambda the two counters were
+  //  kept in scratch memory and every tap stored them back -- VMEM traffic inside the MFMA loop that the stage barriers then waited for)
+  auto mma_stage = [&](auto MBt, auto NTt, f32x16 (&acc)[2][2], const int (&P0)[2], int bufpx, int HWp, int ks, int cursor,
+                       const unsigned char* wbuf, int ntl, int bt, auto&& burst) -> int {
     constexpr int MB = decltype(MBt)::value, NT = decltype(NTt)::value, NB = 32 * NT;
-    bf16x8 fxa[2][MB], fwa[2][NT], fxb[2][MB], fwb[2][NT];
-    auto load_tap = [&](bf16x8 (&fx)[2][MB], bf16x8 (&fw)[2][NT], int tl) {
+    // Fragment lookahead in taps.  A wave with one or two MFMAs per k-step (1 x 1, 2 x 1, 1 x 2 tiles) issues a tap's MFMAs in 64-128
+    // cycles but waits ~250 for the fragments of the next one: two taps ahead (three register sets) the LDS latency is covered; the 2 x 2
+    // tile (8 MFMAs per tap, no registers to spare) relies on its SIMD partner instead.
+    constexpr int D = (MB * NT >= 4) ? 0 : (NTM == 1 ? 2 : 1);        // (the 64-channel variants have registers for one tap of lookahead only)
+    if (a.dbg & 1) { burst(); return cursor; }
+    int ky = cursor >> 8, kx = cursor & 255;
+    bf16x8 fx[D + 1][2][MB], fw[D + 1][2][NT];
+    auto load_tap = [&](bf16x8 (&gx)[2][MB], bf16x8 (&gw)[2][NT], int tl) {
       const int toff = ky * HWp + kx + bufpx;
       const unsigned char* wt = wbuf + tl * NB * 64;
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const int px = P0[m] + toff;
         const int ad = (px << 6) + (((px << 2) & 0x30) ^ (h << 4));
-        fx[0][m] = *reinterpret_cast<const bf16x8*>(lds + ad);
-        fx[1][m] = *reinterpret_cast<const bf16x8*>(lds + (ad ^ 32));
+        gx[0][m] = *reinterpret_cast<const bf16x8*>(lds + ad);
+        gx[1][m] = *reinterpret_cast<const bf16x8*>(lds + (ad ^ 32));
       }
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
-        fw[0][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + wl);
-        fw[1][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ 32));
+        gw[0][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + wl);
+        gw[1][b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ 32));
       }
       if (++kx == ks) { kx = 0; ++ky; }
     };
-    auto step = [&](bf16x8 (&fx)[2][MB], bf16x8 (&fw)[2][NT], bf16x8 (&gx)[2][MB], bf16x8 (&gw)[2][NT], int tl) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_tap(gx, gw, min(tl + 1, ntl - 1));
+    // (the tap cursor may run up to D taps past the stage's last one: such fragments are read inside LDS but never used)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-          for (int b = 0; b < NT; ++b)
-            acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s2][b], fx[s2][m], acc[m][b], 0, 0, 0);
-      constexpr int NM = 2 * MB * NT, NR = 2 * (MB + NT);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < NR - NM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        else if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < SPT; ++q) side(SPT * tl + q);
-    };
-    load_tap(fxa, fwa, 0);
+    for (int d = 0; d < D; ++d) load_tap(fx[d], fw[d], min(d, ntl - 1));
 #pragma unroll
     for (int tl = 0; tl < C6_MAXT; ++tl) {
       if (tl < ntl) {
-        if (tl & 1) step(fxb, fwb, fxa, fwa, tl); else step(fxa, fwa, fxb, fwb, tl);
-      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NM = 2 * MB * NT, NR = 2 * (MB + NT);
+        load_tap(fx[(tl + D) % (D + 1)], fw[(tl + D) % (D + 1)], min(tl + D, ntl - 1));
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) side(SPT * tl + q);
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tl % (D + 1)][s2][b], fx[tl % (D + 1)][s2][m], acc[m][b], 0, 0, 0);
+        if constexpr (D > 0) {
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NR - NM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tl == bt) burst();
       }
     }
-    if (kx == 0) { kx = ks - 1; --ky; } else --kx;             // undo the cursor's run-ahead
+#pragma unroll
+    for (int d = 0; d < D; ++d) { if (kx == 0) { kx = ks - 1; --ky; } else --kx; }     // undo the cursor's run-ahead
+    return (ky << 8) | kx;
   };
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
 
+  bool first_unit = true;
+  float e_reg = (wave == 0 && lane < a.Cm) ? a.e[(long)cur.n * a.Cm + lane] : 0.f;
   while (true) {
+    stamp(2);
+    // this unit's FiLM vector -> LDS (read in the middle op; visible behind the conv A stage barriers); fetched one unit ahead
+    if (wave == 0 && lane < a.Cm) reinterpret_cast<float*>(lds + EB0)[lane] = e_reg;
     if (cur.ks != hb_ks) {                                      // (wave-uniform; every wave is past its reads of the old image: the previous unit ended on a barrier)
-      __syncthreads();
+      stage_barrier();
       zero_hb();
       hb_ks = cur.ks;
     }
     // =========================================== conv A over the (HM x W) region the second conv needs ===========================================
     // this wave's blocks: wave and wave + 8 (32 pixels each; rows of 32, or pairs of rows of 16)
-    const int nvA = (wave + NW < cur.nblkA) ? 2 : 1;
+    const int nvA = (wave + NW < cg.nblkA) ? 2 : 1;
     int P0A[2], mrA[2], mcA[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const int blk = min(wave + NW * m, cur.nblkA - 1);
+      const int blk = min(wave + NW * m, cg.nblkA - 1);
       const int q = blk * 32 + r;
       mrA[m] = q >> tws; mcA[m] = q & (a.W - 1);
-      P0A[m] = mrA[m] * cur.WXp + mcA[m];
+      P0A[m] = mrA[m] * cg.WXp + mcA[m];
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -267,55 +317,79 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
     for (int c = 0; c < nchA; ++c) {
       const bool last_chunk = c == nchA - 1;
       int hmode = 0, nh = 0;
-      if (!last_chunk) { hmode = 1; nh = xpieces(cur.ppt); }
+      if (!last_chunk) { hmode = 1; nh = xpieces(cg.ppt); }
       else if (has_next) {
-        decode(jn, nu);
-        hyx_update(nu);
-        hmode = 2; nh = xpieces(nu.ppt);
+        // Units are dealt round robin (j, j + G, ...): with G a multiple of the tiles per image the successor is the SAME tile of row
+        // n + G / tpi -- same expert, kernel size and padding pattern unless that row belongs to the next expert: no decode, the DMA
+        // source offsets just move by whole images.
+        const int dn = udiv(G, a.m_tpi, a.tpi);
+        if (dn * a.tpi == G && cur.n + dn < cur.rend) {
+          nu = cur; nu.n = cur.n + dn;
+          const unsigned step_b = (unsigned)(dn * a.H * a.W * ca2);
+#pragma unroll
+          for (int k = 0; k < NPW; ++k) hon[k] = hoc[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : hoc[k] + step_b;
+        } else {
+          decode(jn, nu);
+          hyx_update(nu);
+#pragma unroll
+          for (int k = 0; k < NPW; ++k) hon[k] = plan_piece(nu, k);
+        }
+        hmode = 2; nh = xpieces(ppt_of(nu.ks));
+        if (wave == 0 && lane < a.Cm) e_reg = a.e[(long)nu.n * a.Cm + lane];
       }
       const int xbn = XB0 + (par ^ 1) * a.xb_bytes;
-      int ky = 0, kx = 0;
-      for (int tg = 0; tg < cur.ntg; ++tg) {
+      int cursor = 0;
+      for (int tg = 0; tg < cg.ntg; ++tg) {
         const int t0 = tg * a.T;
-        const int ntl = min(a.T, cur.ntaps - t0);
-        __syncthreads();
+        const int ntl = min(a.T, cg.ntaps - t0);
+        stamp(3);
+        stage_barrier(first_unit || c > 0 || tg > 0);
+        stamp(4);
         const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
         WNext wn{0, 0, 0};
-        if (tg + 1 < cur.ntg) wn = WNext{0, baseA(cur, c, t0 + a.T), wpieces(min(a.T, cur.ntaps - t0 - a.T), PPTA)};
-        else if (!last_chunk) wn = WNext{0, baseA(cur, c + 1, 0), wpieces(min(a.T, cur.ntaps), PPTA)};
-        else wn = WNext{1, baseB(cur, 0, 0, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
+        if (tg + 1 < cg.ntg) wn = WNext{0, baseA(cur, c, t0 + a.T), wpieces(min(a.T, cg.ntaps - t0 - a.T), PPTA)};
+        else if (!last_chunk) wn = WNext{0, baseA(cur, c + 1, 0), wpieces(min(a.T, cg.ntaps), PPTA)};
+        else wn = WNext{1, baseB(cur, 0, 0, 0), wpieces(min(a.T, cg.ntaps), PPTB)};
         const int nhs = tg == 0 ? nh : 0;
-        auto side = [&](int k) {
-          if (k < NWP && k < wn.np) issue_wpiece(wn, k, wbn);
-          if (k < NPW && k < nhs) {
-            if (hmode == 2) { hon[k] = plan_piece(nu, k); issue_xpiece(hon[k], k, 0, xbn); }
-            else issue_xpiece(hoc[k], k, c + 1, xbn);
+        auto burst = [&]() {                                    // the next stage's weights, the next chunk's / unit's x pieces
+          issue_wstage(wn, wbn);
+          if (a.dbg & 2) return;
+          if (hmode == 2) {
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) if (k < nhs) issue_xpiece(hon[k], k, 0, xbn);
+          } else {
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) if (k < nhs) issue_xpiece(hoc[k], k, c + 1, xbn);
           }
         };
+        const int bt = min(wave >> 2, ntl - 1);                 // (waves 4-7 one tap later than their SIMD partners 0-3)
         const int bufpx = (XB0 + par * a.xb_bytes) >> 6;
         const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
-        if (nvA == 2) mma_stage(I2{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
-        else mma_stage(I1{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
+        if (nvA == 2) cursor = mma_stage(I2{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
+        else cursor = mma_stage(I1{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
         sp ^= 1;
       }
       par ^= 1;
     }
+    stamp(5);
+    drain_dma();                                              // conv B's first weight stage (issued beside the last stage above) has landed
+    stamp(6);
     // ---- middle op on conv A's accumulators -> intermediate image in LDS (every position of the region: activation, or 0 outside the image)
     {
       typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       bf16* U = (bf16*)a.u;
       bf16* HM = (bf16*)a.hmid;
-      const int WMp = cur.WXp;
+      const int WMp = cg.WXp;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        if (m < nvA) {
+        if (m < nvA && !(a.dbg & 8)) {
           const int mr = mrA[m], mc = mcA[m];
-          const int iy = cur.ty0 - cur.pd + mr;
+          const int iy = cur.ty0 - cg.pd + mr;
           const bool inimg = (unsigned)iy < (unsigned)a.H;
-          const bool owned = mr >= cur.pd && mr < cur.pd + a.TH;
+          const bool owned = mr >= cg.pd && mr < cg.pd + a.TH;
           const long pix = (((long)cur.n * a.H + iy) * a.W + mc) * a.Cm;
-          const int hpx = mr * WMp + mc + cur.pd;
+          const int hpx = mr * WMp + mc + cg.pd;
           const int hsw = (hpx >> 2) & 3;
 #pragma unroll
           for (int b = 0; b < NTM; ++b)
@@ -334,15 +408,15 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
               unsigned ho[4] = {0u, 0u, 0u, 0u};
               if (inimg) {
                 const long eo = pix + c0;
-                const float* ep = a.e + (long)cur.n * a.Cm + c0;
+                const float* ep = reinterpret_cast<const float*>(lds + EB0) + c0;
                 uint32_t r4[8];
                 if (a.p > 0.f) {
                   const long q0 = eo >> 2;
                   philox((uint32_t)q0, (uint32_t)(q0 >> 32), seed_lo, seed_hi, r4);
                   philox((uint32_t)(q0 + 1), (uint32_t)((q0 + 1) >> 32), seed_lo, seed_hi, r4 + 4);
                 }
-                if (a.mode == 0) {
-                  if (owned) *reinterpret_cast<uint4*>(U + eo) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if constexpr (MODE == 0) {
+                  if (owned && !(a.dbg & 4)) *reinterpret_cast<uint4*>(U + eo) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 #pragma unroll
                   for (int j2 = 0; j2 < 4; ++j2) {
                     const bf2 yv = __builtin_bit_cast(bf2, pk[j2]);
@@ -354,7 +428,7 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
                     }
                     ho[j2] = __builtin_bit_cast(unsigned, (bf2){(bf16)f0, (bf16)f1});
                   }
-                  if (owned) *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+                  if (owned && !(a.dbg & 4)) *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
                 } else {
                   // FiLM / mp_silu / dropout backward on the bf16-rounded d(activation): du = g * silu'(u e) * e, de += g * silu'(u e) * u
                   const uint4 uq = *reinterpret_cast<const uint4*>(U + eo);
@@ -395,39 +469,59 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
         }
       }
     }
+    stamp(7);
     // =========================================== conv B over the tile, intermediate read from LDS ===========================================
     {
       const int q = wave * 32 + r;
       const int orow = q >> tws, oc = q & (a.W - 1);
-      const int P0B[2] = {orow * cur.WXp + oc, 0};
+      const int P0B[2] = {orow * cg.WXp + oc, 0};
       const int yy = cur.ty0 + orow;
       for (int nb = 0; nb < nblkB; ++nb) {
         f32x16 accb[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) accb[0][b] = (f32x16)(0.f);
+        // the residual's quads for the epilogue: loaded now, they arrive while the taps below run
+        const bf16* R = (const bf16*)a.res;
+        const long pix = (((long)cur.n * a.H + yy) * a.W + oc) * a.Cb + nb * NBB;
+        constexpr bool RPF = NTB == 1;                        // (the 64-channel variant has no registers left for it: it loads in the epilogue)
+        bf16x4 rq[NTB][2][2];
+        if (RPF && R) {
+#pragma unroll
+          for (int b = 0; b < NTB; ++b)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const long o0 = pix + 32 * b + 16 * p + 4 * h;
+              rq[b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
+              rq[b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+            }
+        }
         for (int c = 0; c < NTM; ++c) {
-          int ky = 0, kx = 0;
-          for (int tg = 0; tg < cur.ntg; ++tg) {
+          int cursor = 0;
+          for (int tg = 0; tg < cg.ntg; ++tg) {
             const int t0 = tg * a.T;
-            const int ntl = min(a.T, cur.ntaps - t0);
-            __syncthreads();
+            const int ntl = min(a.T, cg.ntaps - t0);
+            stamp(8);
+            stage_barrier(c > 0 || tg > 0);
+            stamp(9);
             const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
             WNext wn{0, 0, 0};
-            if (tg + 1 < cur.ntg) wn = WNext{1, baseB(cur, nb, c, t0 + a.T), wpieces(min(a.T, cur.ntaps - t0 - a.T), PPTB)};
-            else if (c + 1 < NTM) wn = WNext{1, baseB(cur, nb, c + 1, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
-            else if (nb + 1 < nblkB) wn = WNext{1, baseB(cur, nb + 1, 0, 0), wpieces(min(a.T, cur.ntaps), PPTB)};
-            else if (has_next) wn = WNext{0, baseA(nu, 0, 0), wpieces(min(a.T, nu.ntaps), PPTA)};
-            auto side = [&](int k) { if (k < NWP && k < wn.np) issue_wpiece(wn, k, wbn); };
+            if (tg + 1 < cg.ntg) wn = WNext{1, baseB(cur, nb, c, t0 + a.T), wpieces(min(a.T, cg.ntaps - t0 - a.T), PPTB)};
+            else if (c + 1 < NTM) wn = WNext{1, baseB(cur, nb, c + 1, 0), wpieces(min(a.T, cg.ntaps), PPTB)};
+            else if (nb + 1 < nblkB) wn = WNext{1, baseB(cur, nb + 1, 0, 0), wpieces(min(a.T, cg.ntaps), PPTB)};
+            else if (has_next) wn = WNext{0, baseA(nu, 0, 0), wpieces(min(a.T, nu.ks * nu.ks), PPTA)};
+            auto burst = [&]() { issue_wstage(wn, wbn); };
+            const int bt = min(wave >> 2, ntl - 1);
             const int bufpx = (HB0 + c * a.hb_plane) >> 6;
             const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
-            mma_stage(I1{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cur.WXp, cur.ks, ky, kx, wbuf, ntl, side);
+            cursor = mma_stage(I1{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
             sp ^= 1;
           }
         }
+        stamp(10);
+        drain_dma();                                          // the next stage's weights (and, long since, the next unit's x chunk) have landed
+        stamp(11);
         // epilogue: y = alpha * acc + beta * res (fp32, one rounding), 16-byte stores
         bf16* Y = (bf16*)a.y;
-        const bf16* R = (const bf16*)a.res;
-        const long pix = (((long)cur.n * a.H + yy) * a.W + oc) * a.Cb + nb * NBB;
 #pragma unroll
         for (int b = 0; b < NTB; ++b)
 #pragma unroll
@@ -436,11 +530,13 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
 #pragma unroll
             for (int q2 = 0; q2 < 8; ++q2) v[q2] = a.alpha * accb[0][b][8 * p + q2];
             if (R) {
-              const long o0 = pix + 32 * b + 16 * p + 4 * h;
-              const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);
-              const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+              if (!RPF) {
+                const long o0 = pix + 32 * b + 16 * p + 4 * h;
+                rq[b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
+                rq[b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+              }
 #pragma unroll
-              for (int q2 = 0; q2 < 4; ++q2) { v[q2] += a.beta * (float)r0[q2]; v[4 + q2] += a.beta * (float)r1[q2]; }
+              for (int q2 = 0; q2 < 4; ++q2) { v[q2] += a.beta * (float)rq[b][p][0][q2]; v[4 + q2] += a.beta * (float)rq[b][p][1][q2]; }
             }
             typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -448,12 +544,15 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
             const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
             const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
             const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
-            *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (!(a.dbg & 4)) *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
       }
     }
+    stamp(12);
     if (!has_next) break;
+    first_unit = false;
     cur = nu;
+    if (cg.pd != ((cur.ks - 1) >> 1)) cg = geo_of(cur.ks);
 #pragma unroll
     for (int k = 0; k < NPW; ++k) hoc[k] = hon[k];
     jn += G;

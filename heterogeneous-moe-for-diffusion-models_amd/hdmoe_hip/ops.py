@@ -988,6 +988,11 @@ def mp_conv_film(x: Tensor, weights, gain, emb: Tensor, p: float, training: bool
 
 
 BLK6 = _os.environ.get("HDMOE_BLK6", "1") != "0"
+# Which blocks take the fused launch.  Measured per layer shape (tools/blk6_bench.py, graph replay, N = 512 rows, experts [3,3,5,5],
+# dropout 0.2; fused vs conv6 + film_silu + conv6): 32 -> 32 at 32x32 108 vs 117 us, 64 -> 32 140 vs 142, 32 -> 32 at 16x16 33 vs 42; but
+# 64 -> 64 at 16x16 76 vs 73, 128 -> 64 98 vs 93, 64 -> 64 at 32x32 306 vs 280: with 64 output channels the unit's phases (conv A, middle op,
+# conv B) run one after the other in a single 8-wave workgroup and the halo recompute is not paid back.  "c32": 32-channel blocks only.
+BLK6_SCOPE = _os.environ.get("HDMOE_BLK6_SCOPE", "c32")
 
 
 def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, gain2: float, emb: Tensor, p: float, training: bool,
@@ -1012,6 +1017,8 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     C = ent1.O
     if ent1.I != Cin or ent2.I != C or ent2.O != C or (seg is None and len(w1s) != 1):
         return None
+    if BLK6_SCOPE == "c32" and C != 32:
+        return None
     p = float(p) if training else 0.0
     e32 = _f32(emb)
     seed = _next_seed() if p > 0.0 else 0
@@ -1020,6 +1027,8 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     y = torch.empty_like(u)
     if call("hdmoe_unet_block_fwd", h, ent1.wf, ent2.wf, u, hb, y, res, e32, seed, step_counter(h.device), p, float(alpha), float(beta), seg,
             len(w1s), ent1.wstride, ent2.wstride, N, H, W, Cin, C, ent1.khs, _dt(h)) != 0:
+        if p > 0.0:
+            _seed_state["ctr"] -= 1                            # nothing was launched: the unfused path draws this salt itself
         return None
     STATS["blk"] += 1
     ws1 = w1s if seg is not None else w1s[0]

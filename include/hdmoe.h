@@ -298,6 +298,7 @@ int hdmoe_unet_block_fwd(const void* x, const void* w1, const void* w2, void* u,
                          unsigned long long seed, const unsigned long long* seed_dev, float p, float alpha, float beta, const int* seg,
                          int ngroups, long w1stride, long w2stride, int N, int H, int W, int Cin, int C, const int* kh, int dtype,
                          HS stream);
+int hdmoe_blk6_debug_stamps(void* buf);   /* development: 8 x 64 u64 device buffer for workgroup 0's in-kernel time stamps, or NULL */
 int hdmoe_unet_block_bwd(const void* dy, const void* wd2, const void* wd1, const void* u, void* du, void* dx, float* de, const float* e,
                          unsigned long long seed, const unsigned long long* seed_dev, float p, float alpha, float alpha_mid, const int* seg,
                          int ngroups, long wd2stride, long wd1stride, int N, int H, int W, int Cin, int C, const int* kh, int dtype,

@@ -1317,7 +1317,9 @@ def test_conv_with_film_epilogue_matches_the_two_launches(C, ks, train):
 
 @pytest.mark.parametrize("Cin,C,HW,ks,train,with_res", [(32, 32, 32, [3, 5], True, True), (64, 64, 16, [3, 3, 5, 5], True, True), (96, 32, 32, [5, 3], True, True),
                                                         (128, 64, 16, [3, 5], False, True), (64, 64, 32, [5, 3], True, False), (32, 32, 32, [7, 3, 5], True, True),
-                                                        (32, 32, 16, [3], False, True), (64, 32, 64, [3, 5], True, True)])
+                                                        (32, 32, 16, [3], False, True), (64, 32, 64, [3, 5], True, True), (64, 64, 16, [7, 3, 5], True, True),
+                                                        (128, 64, 16, [7, 5, 3, 3], True, True), (96, 32, 32, [7, 7, 3], True, True),
+                                                        (32, 32, 32, [3, 3, 3, 5, 5, 5, 7, 7], True, True), (64, 64, 16, [3, 3, 3, 5, 5, 5, 7, 7], False, True)])
 def test_fused_unet_block_matches_the_three_launches(Cin, C, HW, ks, train, with_res):
     """ops.unet_block_fused (csrc/blk6.hip): conv_res1 -> FiLM -> mp_silu -> dropout -> conv_res2 -> mp_sum of Unet_block (reference
     model_components.py:240-253) as one launch with the activation tile in LDS, against conv6 + film_silu + conv6: the same MFMA
@@ -1346,7 +1348,8 @@ def test_fused_unet_block_matches_the_three_launches(Cin, C, HW, ks, train, with
     seg = torch.tensor([0] + cuts + [N], dtype=torch.int32, device=DEV) if G > 1 else None
     gy = torch.randn(N, HW, HW, C, device=DEV).bfloat16()
     out = {}
-    saved = ops.BLK6
+    saved = (ops.BLK6, ops.BLK6_SCOPE)
+    ops.BLK6_SCOPE = "all"                                         # (by default only the 32-channel blocks take the fused launch)
     try:
         for mode in ("warm", "fused", "separate"):
             ops.BLK6 = mode == "fused"
@@ -1371,7 +1374,7 @@ def test_fused_unet_block_matches_the_three_launches(Cin, C, HW, ks, train, with
             for w in list(m.w1) + list(m.w2):
                 w.grad.zero_()
     finally:
-        ops.BLK6 = saved
+        ops.BLK6, ops.BLK6_SCOPE = saved
     (y1, dx1, de1, dr1, dw1), (y2, dx2, de2, dr2, dw2) = out["fused"], out["separate"]
     assert torch.isfinite(y1.float()).all() and float(y1.float().abs().max()) > 0.1
     assert torch.equal(y1, y2), f"max diff {float((y1.float() - y2.float()).abs().max()):.3e}"
