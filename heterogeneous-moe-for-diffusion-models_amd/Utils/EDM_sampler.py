@@ -95,6 +95,13 @@ class EDM_Sampler:
     def sample(self, noise: torch.Tensor, text_emb: torch.Tensor, transition_mean: float, softness: float,
                uncond_text_emb: torch.Tensor = None) -> torch.Tensor:
         device = noise.device
+        if self.use_graph:
+            # the captured evaluation holds no weight-prepare launch when the images were current at capture time: refresh them here,
+            # eagerly, in case the parameters changed since (new checkpoint, an optimizer step)
+            from hdmoe_hip import bank as wbank
+            for m_ in {id(self.model): self.model, id(self.gnet): self.gnet}.values():
+                if isinstance(m_, nn.Module) and getattr(m_, "_hdmoe_bank", None) is not None:
+                    m_._hdmoe_bank.refresh_eval()
         t_steps = self.t_schedule(device)
         x_next = ops.axpby(noise.to(self.dtype), None, float(t_steps[0]), 0.0)
         for i in range(self.num_steps):

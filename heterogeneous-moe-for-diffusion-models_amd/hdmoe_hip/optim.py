@@ -174,6 +174,8 @@ class FusedAdamW(torch.optim.Optimizer):
             ss, _ = grad_norm_sq(clip[0], key=("step", id(self)))
             max_norm = float(clip[1])
         g0 = self.param_groups[0]
+        from . import bank as _bank
+        _bank.note_weights_changed()                          # (the kernel writes the parameters through raw pointers: Tensor._version stays)
         call("hdmoe_mt_adamw", self._table.descs, self._table.chunks, self._table.n, self._table.ntensors, ss, max_norm,
              [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups], len(self.param_groups),
              g0["betas"][0], g0["betas"][1], g0["eps"])
