@@ -122,7 +122,7 @@ def roofline_leg(step_fn, n_steps):
     shapes = {}
     per_shape = {}
     for kind, info, s, e in rec:
-        name = info["fwd_name"] if kind == "conv_fwd" else info["wgrad_name"]
+        name = info["name"] if kind == "fused" else (info["fwd_name"] if kind == "conv_fwd" else info["wgrad_name"])
         sk = f"{name} N={info['N']} HW={info['HW']} O={info['O']} I={info['I']} taps={info['taps']}"
         per_shape.setdefault(sk, []).append((name, info, max(s.elapsed_time(e) - overhead, 0.001)))
     for sk, lst in per_shape.items():
@@ -134,7 +134,7 @@ def roofline_leg(step_fn, n_steps):
             sh[0] += d; sh[1] += 1
             a = agg.setdefault(name, dict(ms=0.0, flops=0.0, n=0, dtype=info["dtype"]))
             a["ms"] += d
-            a["flops"] += conv_flops(info)
+            a["flops"] += conv_flops(info) * info.get("mult", 1.0)     # fused launches: dgrad + wgrad (x 2), conv_res1 + conv_res2 (I = Cin + C)
             a["n"] += 1
     if not agg:
         return None, {}
@@ -147,7 +147,7 @@ def roofline_leg(step_fn, n_steps):
                     avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps, ms_per_step=round(a["ms"] / n_steps, 3))
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     # the expert grouped-GEMM kernels (bf16): the north_star's MFMA-utilisation target is about these, whatever kernel dominates
-    bf = {k: v for k, v in agg.items() if v["dtype"] == "bfloat16" and ("conv6" in k or "wgrad6" in k)}
+    bf = {k: v for k, v in agg.items() if v["dtype"] == "bfloat16" and ("conv6_bf16" in k or "wgrad6_kernel" in k or "bwd6_kernel" in k or "blk6" in k)}
     expert = None
     if bf:
         en, ea = max(bf.items(), key=lambda kv: kv[1]["ms"])
@@ -155,7 +155,7 @@ def roofline_leg(step_fn, n_steps):
         tot_ms = sum(v["ms"] for v in bf.values()); tot_fl = sum(v["flops"] for v in bf.values())
         expert["all_expert_kxk_kernels"] = dict(ms_per_step=round(tot_ms / n_steps, 3), achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                                                 frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK["bfloat16"], 4),
-                                                note="time-weighted over conv6 (fwd+dgrad) and wgrad6 launches, realised routing")
+                                                note="time-weighted over the bf16 expert k x k launches (conv6, wgrad6, bwd6 = dgrad + wgrad, blk6 = fused block), realised routing")
     roofline_leg.expert = expert
     peak = MFMA_PEAK[a["dtype"]]
     ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
@@ -401,12 +401,24 @@ def main():
         print(f"[bench] masked leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
     roof, table = (None, {})
     cpu = None
+    roof_unfused = None
     if rank == 0:
         if not args.no_roofline:
-            roof, table = roofline_leg(local_step, 3)       # per-launch events need eager launches; rank-local (no collective)
+            # per-launch events need eager launches; rank-local (no collective).  Leg 1: the launches of the REPLAYED step (weight-bank
+            # path: dgrad + wgrad in one launch, fused Unet_block, fused router trunks) -> `roofline` = its dominant GEMM-shaped kernel.
+            # Leg 2 (reference point of rounds 1-2): every layer on its own unfused kernels.
+            ops.PROFILE_FUSED = True
+            roof, table = roofline_leg(local_step, 3)
+            expert_in_step = getattr(roofline_leg, "expert", None)
+            ops.PROFILE_FUSED = False
+            roof_unfused, table_u = roofline_leg(local_step, 3)
+            expert_unfused = getattr(roofline_leg, "expert", None)
+            roofline_leg.expert = expert_in_step
+            if roofline_leg.expert is not None and expert_unfused is not None:
+                roofline_leg.expert["unfused_eager_leg"] = {k: expert_unfused[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "ms_per_step", "all_expert_kxk_kernels") if k in expert_unfused}
             if args.dump_kernels:
                 with open(args.dump_kernels, "w") as f:
-                    json.dump(table, f, indent=1)
+                    json.dump({"in_step_launches": table, "unfused_launches": table_u}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             med, cb, cores, nst = cpu_baseline(args.config, kw, bc["module"])
             # metric unit: steps of B samples per second -> a CPU step of cb samples counts as cb/B of a bench step

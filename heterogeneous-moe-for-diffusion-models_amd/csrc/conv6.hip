@@ -101,7 +101,8 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
   if (lds > (size_t)LDS_CAP || T * (NB / 16) > 40) return 1;
   long ub = (tiles + MT - 1) / MT + c.ngroups;
   ub *= a.nblk;
-  const long gcap = wg2 ? 512 : 256;
+  static const long gcap_env = getenv("HDMOE_C6_G") ? atol(getenv("HDMOE_C6_G")) : 0;       // (A/B aid: fewer persistent workgroups leave CUs to the other branches)
+  const long gcap = wg2 ? 512 : (gcap_env > 0 ? gcap_env : 256);
   plan.G = (unsigned)(ub < gcap ? ub : gcap);
   plan.MT = MT; plan.NT = NT; plan.lds = lds;
   return 0;

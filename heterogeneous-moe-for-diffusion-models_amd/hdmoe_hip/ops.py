@@ -92,7 +92,15 @@ def advance_seed(device) -> None:
 # Optional per-launch timing of the GEMM-shaped kernels (bench.py's roofline leg): when PROFILE is a list, every
 # hdmoe_conv_fwd / hdmoe_conv_wgrad launch is bracketed by events on the launch stream and logged with its shape.
 PROFILE = None
+# PROFILE_FUSED: the timed leg keeps the weight-bank path of the replayed step -- dgrad + wgrad in one launch (bwd6 / bwd6s), the fused
+# Unet_block launch (blk6), the fused router trunk, deferred wgrad6 reductions -- and brackets THOSE launches with events
+# (bench.py: roofline = the in-step dominant kernel).  False: every layer on its own unfused kernels (the round-1/2 leg).
+PROFILE_FUSED = False
 _spacer = None
+
+
+def _prof_ok() -> bool:
+    return PROFILE is None or PROFILE_FUSED
 
 
 def _timed(kind: str, info: dict, name: str, *args):
@@ -109,7 +117,7 @@ def _timed(kind: str, info: dict, name: str, *args):
     rc = call(name, *args)
     e.record()
     if rc == 0:
-        if name == "hdmoe_conv_wgrad6":
+        if name == "hdmoe_conv_wgrad6" and "deferred" not in info.get("wgrad_name", ""):
             info = dict(info, wgrad_name="wgrad6_kernel<split> (+ reduce)" if info.get("dtype") == "split_bf16" else "wgrad6_kernel (+ reduce)")
         PROFILE.append((kind, info, s, e))
     return rc
@@ -347,11 +355,12 @@ def _wgrad(info, x, dy, Gs, seg, G, N, H, W, Ho, Wo, I, Cphys, O, ones, khs, kws
         dtc = F32S if split else _dt(x)
         kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, I, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
                                              ctypes.cast(_int_array(kws), ctypes.c_void_p), dtc)
-        if kib > 0 and bank is not None and W6_DEFER and PROFILE is None:
+        if kib > 0 and bank is not None and W6_DEFER and _prof_ok():
             # weight-bank layer: the partial slabs stay in the arena, the bank sums all layers' partials in one batched launch
             ws = _w6_arena_take(x.device, 2 * kib * 256)
             if ws is not None:
-                if call("hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc, 1) == 0:
+                if _timed("conv_wgrad", dict(info, dtype="split_bf16" if split else info.get("dtype"), wgrad_name="wgrad6_kernel<split> (deferred reduce)" if split else "wgrad6_kernel (deferred reduce)"),
+                          "hdmoe_conv_wgrad6", x, dy, Gs, seg, G, N, H, W, I, O, khs, kws, pts, pts, ws, ws.numel() * 4, dtc, 1) == 0:
                     bank.defer_w6(list(Gs), seg, ws, [G, N, H, W, I, O, dtc, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     STATS["w6_defer"] += 1
                     return
@@ -445,7 +454,7 @@ class _MPConvFn(torch.autograd.Function):
         need_gain = gains is not None and any(nig[4 + G + g] for g in range(G))
         need_w = any(nig[4 + g] for g in range(G)) or need_gain
         fused = False
-        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and PROFILE is None and x.dtype == torch.bfloat16 and not split
+        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and _prof_ok() and x.dtype == torch.bfloat16 and not split
                 and not ones and Ho == H and Wo == W and Cphys == I and set(khs) == {3, 5} and khs == kws):
             # input gradient + (deferred) weight gradient of a 3x3 / 5x5 expert layer in one launch (csrc/bwd6.hip)
             from ._lib import lib, _int_array
@@ -457,15 +466,16 @@ class _MPConvFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 Opad = (O + 15) // 16 * 16
                 wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
-                if call("hdmoe_conv_bwd6", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, N, H, W, I, O, khs, kws, pts, pts, alpha,
-                        ws, ws.numel() * 4, _dt(x)) == 0:
+                if _timed("fused", dict(name="bwd6_kernel", dtype="bfloat16", seg=seg, N=N, HW=H * W, O=O, I=I, taps=[a * b for a, b in zip(khs, kws)], mult=2.0),
+                          "hdmoe_conv_bwd6", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, N, H, W, I, O, khs, kws, pts, pts, alpha,
+                          ws, ws.numel() * 4, _dt(x)) == 0:
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, _dt(x), 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
                     STATS["bwd6"] += 1
                 else:
                     dx = None
-        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and PROFILE is None and split and not ones and Ho == H and Wo == W
+        if (nig[0] and need_w and ctx.ent is not None and BWD6 and W6_DEFER and _prof_ok() and split and not ones and Ho == H and Wo == W
                 and Cphys == I and set(khs) == {3} and khs == kws):
             # the same for a router-trunk layer (fp32 tensors, split-bf16 arithmetic)
             from ._lib import lib, _int_array
@@ -477,8 +487,9 @@ class _MPConvFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 Opad = (O + 15) // 16 * 16
                 wdstride = 9 * I * Opad
-                if call("hdmoe_conv_bwd6s", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, G * wdstride, N, H, W, I, O, khs, kws, pts, pts,
-                        alpha, ws, ws.numel() * 4, None, None, 0, 1 if TRUNK_BWD_BF16 else 0) == 0:
+                if _timed("fused", dict(name="bwd6s_kernel", dtype="bfloat16" if TRUNK_BWD_BF16 else "split_bf16", seg=seg, N=N, HW=H * W, O=O, I=I, taps=[9] * G, mult=2.0),
+                          "hdmoe_conv_bwd6s", x, dy, ctx.wd, dx, list(ctx.ent.G), seg, G, wdstride, G * wdstride, N, H, W, I, O, khs, kws, pts, pts,
+                          alpha, ws, ws.numel() * 4, None, None, 0, 1 if TRUNK_BWD_BF16 else 0) == 0:
                     ctx.bank.defer_w6(list(ctx.ent.G), seg, ws, [G, N, H, W, I, O, F32S, 0] + [int(k) for k in khs] + [0] * (8 - len(khs)))
                     ctx.bank.note_backward(ctx.ent)
                     fused = True
@@ -1004,7 +1015,7 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     launch wrote), so the backward is unchanged."""
     global _PRECOMP
     w1s, w2s = list(w1s), list(w2s)
-    if not (BLK6 and _bank.ACTIVE is not None and PROFILE is None and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_cuda):
+    if not (BLK6 and _bank.ACTIVE is not None and _prof_ok() and h.dtype == torch.bfloat16 and h.ndim == 4 and h.is_cuda):
         return None
     if res is not None and (res.dtype != h.dtype or not res.is_contiguous()):
         return None
@@ -1025,8 +1036,9 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     u = torch.empty((N, H, W, C), dtype=h.dtype, device=h.device)
     hb = torch.empty_like(u)
     y = torch.empty_like(u)
-    if call("hdmoe_unet_block_fwd", h, ent1.wf, ent2.wf, u, hb, y, res, e32, seed, step_counter(h.device), p, float(alpha), float(beta), seg,
-            len(w1s), ent1.wstride, ent2.wstride, N, H, W, Cin, C, ent1.khs, _dt(h)) != 0:
+    if _timed("fused", dict(name="blk6_kernel (fwd)", dtype="bfloat16", seg=seg, N=N, HW=H * W, O=C, I=Cin + C, taps=[k * k for k in ent1.khs], mult=1.0),
+              "hdmoe_unet_block_fwd", h, ent1.wf, ent2.wf, u, hb, y, res, e32, seed, step_counter(h.device), p, float(alpha), float(beta), seg,
+              len(w1s), ent1.wstride, ent2.wstride, N, H, W, Cin, C, ent1.khs, _dt(h)) != 0:
         if p > 0.0:
             _seed_state["ctr"] -= 1                            # nothing was launched: the unfused path draws this salt itself
         return None
@@ -1734,7 +1746,8 @@ class _TrunkFn(torch.autograd.Function):
             slots = lib().hdmoe_conv_split_stats_slots(H, W, O)
             y = torch.empty((N, H, W, O), dtype=torch.float32, device=x.device)
             ws = torch.empty((N, max(slots, 1), 2), dtype=torch.float32, device=x.device)
-            if slots < 1 or call("hdmoe_conv_fwd_split_gn", inp, ent.wf, y, sc, sh, 1, ws, ent.wstride, ent.wstride, N, H, W, I, O, 1.0) != 0:
+            if slots < 1 or _timed("fused", dict(name=f"conv6_split_kernel<{2 if O % 64 == 0 else 1}> (GroupNorm folded)", dtype="split_bf16", seg=None, N=N, HW=S, O=O, I=I, taps=[9], mult=1.0),
+                                   "hdmoe_conv_fwd_split_gn", inp, ent.wf, y, sc, sh, 1, ws, ent.wstride, ent.wstride, N, H, W, I, O, 1.0) != 0:
                 raise RuntimeError("router trunk: layer outside the split conv kernel's domain (ops.trunk_ok should have said so)")
             sc = torch.empty((N, O), dtype=torch.float32, device=x.device)
             sh = torch.empty_like(sc)
@@ -1788,8 +1801,9 @@ class _TrunkFn(torch.autograd.Function):
             isc, ish = (None, None) if l == 0 else (saved[5 * (l - 1) + 1], saved[5 * (l - 1) + 2])
             da = torch.empty_like(xin)
             wdstride = 9 * I * ((O + 15) // 16 * 16)
-            if call("hdmoe_conv_bwd6s", xin, dy, ent.wd, da, list(ent.G), None, 1, wdstride, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
-                    arena, arena.numel() * 4, isc, ish, 1, 1 if TRUNK_BWD_BF16 else 0) != 0:
+            if _timed("fused", dict(name="bwd6s_kernel", dtype="bfloat16" if TRUNK_BWD_BF16 else "split_bf16", seg=None, N=N, HW=S, O=O, I=I, taps=[9], mult=2.0),
+                      "hdmoe_conv_bwd6s", xin, dy, ent.wd, da, list(ent.G), None, 1, wdstride, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
+                      arena, arena.numel() * 4, isc, ish, 1, 1 if TRUNK_BWD_BF16 else 0) != 0:
                 raise RuntimeError("router trunk backward: layer outside the fused backward kernel's domain")
             bank.defer_w6(list(ent.G), None, arena, [1, N, H, W, I, O, F32S, 0, 3, 0, 0, 0, 0, 0, 0, 0])
             bank.note_backward(ent)
@@ -1803,7 +1817,7 @@ class _TrunkFn(torch.autograd.Function):
 def trunk_ok(x: Tensor, convs) -> bool:
     """Can Router.hard_route take the fused path?  bf16 compute mode with split-bf16 trunks, every conv a ready weight-bank entry inside the
     split kernels' domain, and the deferred weight-gradient path on."""
-    if not (TRUNK_FUSED and ROUTER_SPLIT and BWD6 and W6_DEFER and PROFILE is None and _bank.ACTIVE is not None):
+    if not (TRUNK_FUSED and ROUTER_SPLIT and BWD6 and W6_DEFER and _prof_ok() and _bank.ACTIVE is not None):
         return False
     if x.dtype != torch.float32 or x.ndim != 4:
         return False
