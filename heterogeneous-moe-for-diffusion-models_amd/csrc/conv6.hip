@@ -58,6 +58,7 @@ int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {
   static const int dbg = getenv("HDMOE_C6_DBG") ? atoi(getenv("HDMOE_C6_DBG")) : 0;
   a.dbg = dbg;
   a.stamps = (unsigned long long*)g_c6_stamps;
+  a.w_rowpitch = c.Cin; a.w_tapstride = c.Cout * c.Cin; a.gbias = nullptr;
   a.film_e = nullptr; a.film_h = nullptr; a.film_seed_dev = nullptr; a.film_seed_lo = 0; a.film_seed_hi = 0; a.film_p = 0.f;
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.ks[g] = c.kh[g]; a.pt[g] = c.pt[g]; a.pl[g] = c.pl[g]; a.order[g] = g; }
   for (int i = 1; i < c.ngroups; ++i)                       // groups by descending kernel size (longest units first)

@@ -94,7 +94,7 @@ DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
       u.n[m] = row0 + img; u.ty0[m] = tyi * a.TH; u.tx0[m] = (ti - tyi * a.tiles_x) * a.TW;
     }
   };
-  auto wbase_of = [&](const C6Unit<MT>& u) { return (int)(((long)u.g * a.wstride + (long)u.nbk * NB * a.Cin) * 2); };
+  auto wbase_of = [&](const C6Unit<MT>& u) { return (int)(((long)u.g * a.wstride + (long)u.nbk * NB * a.w_rowpitch) * 2); };
 
   // ---- per-lane source offsets (bytes from x, channel chunk 0) of this wave's halo pieces of a unit; ~0 = padding (reads as zero).
   // The (row, column) of a piece's pixel inside the halo tile depends on the kernel size only: kept packed in hyx[] and recomputed
@@ -136,14 +136,14 @@ DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
   auto hpieces = [&](int ppt) { return (MT * ppt + NW - 1) / NW; }; // pieces per wave (the buffer is padded to NW x that many pieces)
   // weights of one stage: taps [t0, t0 + ntl) x 32 channels of chunk c -> [tap][NB rows][64 B] at wbo.  Piece pi = wave + NW k is
   // tap pi / PPT, rows 16 * (pi % PPT) ..: with NW % PPT == 0 only the tap depends on k.
-  const unsigned wlo = (unsigned)((((wave / PPT) * a.Cout + (wave % PPT) * 16 + prow) * a.Cin) * 2 + csl);
-  const int wkstep = (NW / PPT) * a.Cout * a.Cin * 2;          // bytes between a wave's consecutive pieces
+  const unsigned wlo = (unsigned)(((wave / PPT) * a.w_tapstride + ((wave % PPT) * 16 + prow) * a.w_rowpitch) * 2 + csl);
+  const int wkstep = (NW / PPT) * a.w_tapstride * 2;           // bytes between a wave's consecutive pieces
   // one piece (k-th of this wave) of the stage whose first byte inside the weight image is sb
   auto issue_wpiece = [&](int sb, int k, int wbo) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wlo, sb + k * wkstep, 0, 0);
   };
   auto wpieces = [&](int ntl) { return max(0, (ntl - wave / PPT + (NW / PPT) - 1) / (NW / PPT)); };   // this wave's share of a stage
-  auto stage_base = [&](int wbase, int c, int t0) { return wbase + (t0 * a.Cout * a.Cin + c * 32) * 2; };
+  auto stage_base = [&](int wbase, int c, int t0) { return wbase + (t0 * a.w_tapstride + c * 32) * 2; };
 
   int j = bid;
   if (j >= total) return;
@@ -325,8 +325,17 @@ DEVI void conv6_body(const C6Args& a, const int bid, const int G) {
           for (int p = 0; p < 2; ++p) {
             // quads 2p (channels 16p + 4h ..) and 2p+1 (channels 16p + 8 + 4h ..) of this lane
             float v[8];
+            if (a.gbias && ok) {                                    // per-expert bias map (the folded ones channel), inside the alpha scale
+              const float* gb = a.gbias + (((long)cur.g * a.H + yy) * a.W + xx) * a.Cout + cur.nbk * NB + 32 * b + 16 * p + 4 * h;
+              const float4 g0 = *reinterpret_cast<const float4*>(gb), g1 = *reinterpret_cast<const float4*>(gb + 8);
+              v[0] = a.alpha * (acc[m][b][8 * p] + g0.x); v[1] = a.alpha * (acc[m][b][8 * p + 1] + g0.y);
+              v[2] = a.alpha * (acc[m][b][8 * p + 2] + g0.z); v[3] = a.alpha * (acc[m][b][8 * p + 3] + g0.w);
+              v[4] = a.alpha * (acc[m][b][8 * p + 4] + g1.x); v[5] = a.alpha * (acc[m][b][8 * p + 5] + g1.y);
+              v[6] = a.alpha * (acc[m][b][8 * p + 6] + g1.z); v[7] = a.alpha * (acc[m][b][8 * p + 7] + g1.w);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = a.alpha * acc[m][b][8 * p + e];
+              for (int e = 0; e < 8; ++e) v[e] = a.alpha * acc[m][b][8 * p + e];
+            }
             if (R && ok) {                                          // residual added in fp32, before the one rounding to bf16
               const long o0 = pix + 32 * b + 16 * p + 4 * h;
               const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);

@@ -18,6 +18,10 @@ struct C6Args {
   int hb_bytes, wb_bytes;             // bytes of one halo buffer / one weight buffer
   int xbytes, wbytes;                 // extents of x and of the weight image (buffer descriptors; < 4 GB)
   unsigned m_nblk, m_T, m_tpi, m_tx;  // 2^32 / d + 1 reciprocals of nblk, T, tpi, tiles_x
+  int w_rowpitch, w_tapstride;        // weight image geometry in elements: between consecutive output rows / consecutive taps (default Cin, Cout * Cin);
+                                      // larger values read a [tap][rows][pitch] image with more channels / rows than this conv uses
+                                      // (the ones-channel layer of Unet_expert: hdmoe_conv6_ones_fwd / _bwd)
+  const float* gbias;                 // optional fp32 [group][H][W][Cout]: y = alpha * (acc + gbias[g][yy][xx][:]) + beta * res
   int dbg;                            // development ablations: 1 skip the MFMA loop, 2 skip the in-loop DMA, 4 skip the stores
   unsigned long long* stamps;         // development: s_memtime stamps of workgroup 0 ([wave][64] slots), or null
   // fused FiLM epilogue (Unet_block, reference model_components.py:242-246): besides y the kernel writes

@@ -160,6 +160,39 @@ __global__ void upsample2_kernel(T* out, const T* x, int Ho, int Wo, int C, floa
   }
 }
 
+// 16-byte vector forms (C a multiple of the vector width): one thread per output vector, 32-bit index math per row
+template <typename T>
+__global__ void pool2_vec_kernel(T* out, const T* x, int Ho, int Wo, int cv, float scale, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(i, nv) {
+    const long row = i / ((long)Wo * cv);                      // (sample, output row)
+    const int rem = (int)(i - row * ((long)Wo * cv));
+    const int w = rem / cv, c = rem - w * cv;
+    const T* p = x + ((row * 2) * (2 * Wo) + 2 * w) * (long)cv * W + (long)c * W;
+    const long rs = (long)2 * Wo * cv * W;
+    float a[W], b[W], d[W], e[W];
+    vload<T>(a, p); vload<T>(b, p + (long)cv * W); vload<T>(d, p + rs); vload<T>(e, p + rs + (long)cv * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) a[j] = scale * (a[j] + b[j] + d[j] + e[j]);
+    vstore<T>(out + i * W, a);
+  }
+}
+template <typename T>
+__global__ void upsample2_vec_kernel(T* out, const T* x, int Ho, int Wo, int cv, float scale, long nv) {
+  constexpr int W = VT<T>::W;
+  GRID_STRIDE(i, nv) {
+    const long row = i / ((long)Wo * cv);                      // (sample, output row): sample = row / Ho, h = row % Ho
+    const int rem = (int)(i - row * ((long)Wo * cv));
+    const int w = rem / cv, c = rem - w * cv;
+    const long s = row / Ho; const int h = (int)(row - s * Ho);
+    float a[W];
+    vload<T>(a, x + (((s * (Ho / 2) + h / 2) * (Wo / 2) + w / 2) * (long)cv + c) * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) a[j] *= scale;
+    vstore<T>(out + i * W, a);
+  }
+}
+
 // ---------------------------------------------------------------- sequence reduce / broadcast  ([N][S][C] <-> fp32 [N][C])
 template <typename T>
 __global__ void seq_reduce_kernel(float* out, const T* x, long S, int C, float scale, int chunk) {
@@ -944,12 +977,14 @@ int hdmoe_cat2_bwd(void* da, void* db, const void* dout, float wa, float wb, int
 }
 int hdmoe_pool2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, hipStream_t stream) {
   const long n = (long)N * Ho * Wo * C;
-  DT_SWITCH(dtype, L1D(pool2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
+  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(x)) L1D(pool2_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, Ho, Wo, C / VT<T>::W, scale, n / VT<T>::W);
+                   else L1D(pool2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
 }
 int hdmoe_upsample2(void* out, const void* x, int N, int Ho, int Wo, int C, float scale, int dtype, hipStream_t stream) {
   if ((Ho | Wo) & 1) return HDMOE_EINVAL;
   const long n = (long)N * Ho * Wo * C;
-  DT_SWITCH(dtype, L1D(upsample2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
+  DT_SWITCH(dtype, if (C % VT<T>::W == 0 && al16(out) && al16(x)) L1D(upsample2_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, Ho, Wo, C / VT<T>::W, scale, n / VT<T>::W);
+                   else L1D(upsample2_kernel<T>, n, (T*)out, (const T*)x, Ho, Wo, C, scale, n))
 }
 int hdmoe_seq_reduce(float* out, const void* x, int N, long S, int C, float scale, int dtype, hipStream_t stream) {
   if (N > 65535 || C > 8192) return HDMOE_EINVAL;

@@ -425,6 +425,16 @@ class _MPConvFn(torch.autograd.Function):
         y = pre if pre is not None else torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
         req = _FILM_REQ
         fused_film = pre is not None                          # (output already computed by the fused block kernel, ops.unet_block_fused)
+        ctx.ones6 = False
+        if (ones and ONES6 and pre is None and ent is not None and not split and res is None and x.dtype == torch.bfloat16 and _prof_ok()
+                and Ho == H and Wo == W and khs == kws):
+            # torch.cat([x, ones]) (reference model_components.py:416): the 32 real channels on conv6, the ones channel as a bias map (csrc/ones6.hip)
+            gb = torch.empty((G, H, W, O), dtype=torch.float32, device=x.device)
+            if _timed("fused", dict(name="conv6_bf16_kernel (ones-channel layer)", dtype="bfloat16", seg=seg, N=N, HW=H * W, O=O, I=Cphys, taps=[a * b for a, b in zip(khs, kws)], mult=1.0),
+                      "hdmoe_conv6_ones_fwd", x, wf, y, gb, alpha, seg, G, wstride, N, H, W, Cphys, O, Ipad, khs, dtc) == 0:
+                fused_film = True
+                ctx.ones6 = True
+                STATS["ones6"] += 1
         if (pre is None and req is not None and ent is not None and not split and res is None and not ones and x.dtype == torch.bfloat16 and PROFILE is None
                 and Ho == H and Wo == W and Cphys == I):
             # FiLM + mp_silu + dropout as a second output of this conv's epilogue (ops.mp_conv_film): one launch less on the branch's chain
@@ -496,6 +506,29 @@ class _MPConvFn(torch.autograd.Function):
                     STATS["bwd6s"] += 1
                 else:
                     dx = None
+        if ctx.ones6 and need_w and ctx.ent is not None:
+            # the ones-channel layer: dgrad on conv6, weight gradient on wgrad6 + pixel sums of dy (csrc/ones6.hip)
+            from ._lib import lib, _int_array
+            import ctypes
+            kib = lib().hdmoe_conv_wgrad6_ws_kib(G, N, H, W, Cphys, O, ctypes.cast(_int_array(khs), ctypes.c_void_p),
+                                                 ctypes.cast(_int_array(kws), ctypes.c_void_p), _dt(x))
+            if kib > 0:
+                key = (x.device, torch.cuda.current_stream().stream_id)
+                ws = _w6_ws.get(key)
+                if ws is None or ws.numel() < kib * 256:
+                    ws = torch.empty(kib * 256, dtype=torch.float32, device=x.device)
+                    _w6_ws[key] = ws
+                S = torch.empty((G, H, W, O), dtype=torch.float32, device=x.device)
+                g32 = [_zeros((kh * kw, O, Cphys), torch.float32, x.device) for kh, kw in zip(khs, kws)]
+                dxo = torch.empty_like(x) if nig[0] else None
+                Opad = (O + 15) // 16 * 16
+                wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
+                if _timed("fused", dict(name="conv6 dgrad + wgrad6 (ones-channel layer)", dtype="bfloat16", seg=seg, N=N, HW=H * W, O=O, I=Cphys, taps=[a * b for a, b in zip(khs, kws)], mult=2.0 if nig[0] else 1.0),
+                          "hdmoe_conv6_ones_bwd", x, dy, ctx.wd, dxo, list(ctx.ent.G), S, g32, seg, G, wdstride, N, H, W, Cphys, O, Opad, khs, alpha,
+                          ws, ws.numel() * 4, _dt(x)) == 0:
+                    dx = dxo
+                    ctx.bank.note_backward(ctx.ent)
+                    fused = True
         if nig[0] and not fused:
             Opad = (O + 15) // 16 * 16
             wdstride = max(a * b for a, b in zip(khs, kws)) * I * Opad
@@ -998,6 +1031,7 @@ def mp_conv_film(x: Tensor, weights, gain, emb: Tensor, p: float, training: bool
     return _FilmSiluFn.apply(y, req.emb, p, req.seed)
 
 
+ONES6 = _os.environ.get("HDMOE_ONES6", "1") != "0"          # the 33-channel first conv of Unet_expert on conv6 / wgrad6 (csrc/ones6.hip)
 BLK6 = _os.environ.get("HDMOE_BLK6", "1") != "0"
 # Which blocks take the fused launch.  Measured per layer shape (tools/blk6_bench.py, graph replay, N = 512 rows, experts [3,3,5,5],
 # dropout 0.2; fused vs conv6 + film_silu + conv6): 32 -> 32 at 32x32 108 vs 117 us, 64 -> 32 140 vs 142, 32 -> 32 at 16x16 33 vs 42; but

@@ -286,6 +286,17 @@ int hdmoe_edm_loss_bwd(float* dD, float* dlv, float* dpU, float* dpV, float* drU
                        const float* sse, const float* denoised, const float* target, const float* log_var, const float* rU,
                        const float* rV, int B, long L, int E, float unet_bal, float vit_bal, float z_bal, HS stream);
 
+/* ---- the 33-channel first conv of Unet_expert (torch.cat([x, ones]), reference models/model_components.py:416) on the conv6 / wgrad6
+ * kernels (csrc/ones6.hip): the ones channel becomes a per-expert border-aware bias map, its weight gradient a sum of dy over pixel
+ * rectangles.  wf [g][tap][O][Ipad] / wd [g][tap][C + 1][Opad]: the weight images of the (C + 1)-channel layer; gbias, S: fp32
+ * workspaces [ngroups][H][W][O]; G33: weight-gradient slabs [tap][O][C + 1] (+=); G32: zeroed workspace slabs [tap][O][C]; ws: as
+ * hdmoe_conv_wgrad6.  Both return 1 without launching anything outside the domain (bf16, conv6 shapes, k in {3, 5} for the backward). */
+int hdmoe_conv6_ones_fwd(const void* x, const void* wf, void* y, float* gbias, float alpha, const int* seg, int ngroups, long wstride,
+                         int N, int H, int W, int C, int O, int Ipad, const int* kh, int dtype, HS stream);
+int hdmoe_conv6_ones_bwd(const void* x, const void* dy, const void* wd, void* dx, float* const* G33, float* S, float* const* G32, const int* seg,
+                         int ngroups, long wdstride, int N, int H, int W, int C, int O, int Opad, const int* kh, float alpha, void* ws, long ws_bytes,
+                         int dtype, HS stream);
+
 /* ---- K3+K4 fused: Unet_block main branch as one persistent launch (csrc/blk6.hip; reference models/model_components.py:240-253) ----
  * forward:  u = conv(x, w1); h = dropout_p(mp_silu(u * e[n][c])); y = alpha * conv(h, w2) + beta * res   (u, h, y written; the
  *           activation tile stays in LDS between the two convs).  x [N][H][W][Cin], u / h / y / res [N][H][W][C] bf16, e fp32 [N][C];

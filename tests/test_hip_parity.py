@@ -1386,6 +1386,61 @@ def test_fused_unet_block_matches_the_three_launches(Cin, C, HW, ks, train, with
         close_scaled(a, b, 1e-5, msg="dw")
 
 
+@pytest.mark.parametrize("ks,HW", [([3, 5], 32), ([3, 3, 5, 5], 32), ([5], 16), ([7, 3], 32)])
+def test_ones_channel_layer_on_conv6_matches_the_general_kernels(ks, HW):
+    """The first conv of Unet_expert reads torch.cat([x, ones]) (reference model_components.py:416).  csrc/ones6.hip runs its 32 real
+    channels on conv6 / wgrad6 and turns the ones channel into a border-aware bias map (forward) and pixel-rectangle sums of dy
+    (weight gradient); the general kernels evaluate the 33-channel conv directly.  Same function, different summation order: outputs
+    agree to a bf16 ulp, gradients to fp32 summation noise.  [7, 3]: the backward has no wgrad6 for 7x7 and takes the general path."""
+    import hdmoe_hip
+    from hdmoe_hip import ops, bank as wbank
+    from oracle import hdmoe_oracle as O
+    torch.manual_seed(3)
+    G, C, Oc = len(ks), 32, 32
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(Oc, C + 1, k, k)) for k in ks])
+    m = M().to(DEV)
+    N = 9
+    x = torch.randn(N, HW, HW, C, device=DEV).bfloat16()
+    cuts = sorted(torch.randint(1, N, (G - 1,)).tolist())
+    seg = torch.tensor([0] + cuts + [N], dtype=torch.int32, device=DEV) if G > 1 else None
+    gy = torch.randn(N, HW, HW, Oc, device=DEV).bfloat16()
+    out = {}
+    saved = ops.ONES6
+    try:
+        for mode in ("warm", "ones6", "general"):
+            ops.ONES6 = mode != "general"
+            ops.STATS.clear()
+            wbank.bank_for(m).begin_step(False)
+            xx = x.clone().requires_grad_(True)
+            y = ops.mp_conv(xx, list(m.ws) if seg is not None else m.ws[0], 0.9, seg=seg, ones=True)
+            y.backward(gy)
+            wbank.deactivate()
+            torch.cuda.synchronize()
+            if mode == "ones6":
+                assert ops.STATS["ones6"] == 1
+            out[mode] = (y.detach().float(), xx.grad.float().clone(), [w.grad.clone() for w in m.ws])
+            for w in m.ws:
+                w.grad.zero_()
+    finally:
+        ops.ONES6 = saved
+    (y1, dx1, dw1), (y2, dx2, dw2) = out["ones6"], out["general"]
+    close_scaled(y1, y2, 8e-3, msg="y")                            # one bf16 ulp of the largest output
+    close_scaled(dx1, dx2, 8e-3, msg="dx")
+    for a, b in zip(dw1, dw2):
+        close_scaled(a, b, 2e-4, msg="dw")
+        close_scaled(a[:, C], b[:, C], 2e-4, msg="dw of the ones channel")
+    # and against the CPU oracle on the first expert's rows (the reference's own arithmetic in fp32)
+    n1 = int(seg[1]) if seg is not None else N
+    xc = x[:n1].float().cpu().permute(0, 3, 1, 2)
+    xin = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
+    ref = O.mp_conv(xin, m.ws[0].detach().cpu(), 0.9).permute(0, 2, 3, 1)
+    close_scaled(y1[:n1], ref, 2e-2, msg="y vs oracle")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_silu_branch_and_cat_silu_match_the_separate_ops(dtype):
     """ops.silu_branch / ops.mp_cat_silu (decoder-block entry: the block input feeds mp_silu and the skip / residual path) against
