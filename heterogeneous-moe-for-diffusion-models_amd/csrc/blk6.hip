@@ -27,12 +27,12 @@
 
 namespace {
 
-template <int NTM, int NTB, int MODE>
-__global__ __launch_bounds__(64 * C6_NW) void blk6_kernel(B6Args a) {
-  blk6_body<NTM, NTB, MODE>(a, blockIdx.x, gridDim.x);
+template <int NW, int NTM, int NTB, int MODE>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void blk6_kernel(B6Args a) {
+  blk6_body<NW, NTM, NTB, MODE>(a, blockIdx.x, gridDim.x);
 }
 
-struct B6Plan { B6Args a; int NTM, NTB; unsigned G; size_t lds; };
+struct B6Plan { B6Args a; int NW, NTM, NTB; unsigned G; size_t lds; };
 void* g_b6_stamps = nullptr;
 constexpr int B6_EB = 256;                    // bytes of LDS behind the weight buffers: the unit's FiLM vector (<= 64 floats)
 
@@ -40,8 +40,6 @@ int blk6_plan(const void* x, const void* wa, const void* wb, void* y, const void
               long wb_stride, int N, int H, int W, int Ca, int Cm, int Cb, const int* ks, B6Plan& plan) {
   static const bool off = getenv("HDMOE_BLK6") && atoi(getenv("HDMOE_BLK6")) == 0;
   if (off || !(W == 16 || W == 32) || Ca % 32 || Cb % 32 || !(Cm == 32 || Cm == 64) || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return 1;
-  const int TH = 256 / W;
-  if (H % TH) return 1;
   int maxk = 0;
   for (int g = 0; g < ngroups; ++g) {
     if (ks[g] != 3 && ks[g] != 5 && ks[g] != 7) return 1;
@@ -59,34 +57,57 @@ int blk6_plan(const void* x, const void* wa, const void* wb, void* y, const void
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.ks[g] = g < ngroups ? ks[g] : ks[0]; a.order[g] = g; }
   for (int i = 1; i < ngroups; ++i)
     for (int k = i; k > 0 && a.ks[a.order[k]] > a.ks[a.order[k - 1]]; --k) { const int t = a.order[k]; a.order[k] = a.order[k - 1]; a.order[k - 1] = t; }
-  a.TH = TH; a.tpi = H / TH;
   const int NTM = Cm / 32, NTB = Cb % 64 == 0 ? 2 : 1;
-  const int ppt = ((TH + 2 * (maxk - 1)) * (W + maxk - 1) + 15) / 16;
-  if (ppt > 48) return 1;
-  a.xb_bytes = C6_NW * ((ppt + C6_NW - 1) / C6_NW) * 1024;
-  a.hb_plane = (((TH + maxk - 1) * (W + maxk - 1) * 64) + 1023) / 1024 * 1024;
   const int nbmax = 32 * (NTM > NTB ? NTM : NTB);
-  int best = 0, best_stages = 1 << 30;
-  for (int t = 9; t >= 2; --t) {
-    if (t * (nbmax / 16) > 40 || 2 * a.xb_bytes + NTM * a.hb_plane + 2 * t * nbmax * 64 + B6_EB > 160 * 1024) continue;
-    int stages = 0;
-    for (int g = 0; g < ngroups; ++g) stages += (ks[g] * ks[g] + t - 1) / t;
-    if (stages <= best_stages) { best_stages = stages; best = t; }
-  }
   static const int force_t = getenv("HDMOE_B6_T") ? atoi(getenv("HDMOE_B6_T")) : 0;
-  if (force_t && force_t >= 2 && force_t <= 9 && force_t * (nbmax / 16) <= 40 && 2 * a.xb_bytes + NTM * a.hb_plane + 2 * force_t * nbmax * 64 + B6_EB <= 160 * 1024) best = force_t;
-  if (!best) return 1;
-  a.T = best; a.wb_bytes = best * nbmax * 64;
+  static const int force_nw = getenv("HDMOE_B6_NW") ? atoi(getenv("HDMOE_B6_NW")) : 0;
+  // Geometry candidates, best first: 4-wave workgroups, two per CU (<= 80 KB of LDS each, one x buffer, conv A over <= 12 blocks), on
+  // the 256-pixel tile or -- 64-channel layers, whose intermediate image is twice as large -- on a 128-pixel tile; else one 8-wave
+  // workgroup per CU with two x buffers.
+  struct Cand { int nw, th; };
+  const Cand cands[3] = {{4, 256 / W}, {8, 256 / W}, {4, 128 / W}};     // (128-pixel tiles measured slower than the 8-wave form: last resort)
+  bool found = false;
+  for (const Cand& cd : cands) {
+    if ((force_nw == 4 || force_nw == 8) && cd.nw != force_nw) continue;
+    const int th = cd.th;
+    if (th < 4 || H % th || (th * W) % 32) continue;
+    if (cd.nw == 4 && (th * W == 128) && NTM != 2) continue;
+    const int ppt = ((th + 2 * (maxk - 1)) * (W + maxk - 1) + 15) / 16;
+    const int nblkA = (th + maxk - 1) * W / 32;
+    if (ppt > 48 || ((th + maxk - 1) * W) % 32) continue;
+    if (cd.nw == 4 && (nblkA > (NTM == 2 ? 8 : 12) || ppt > 36)) continue;
+    const int xb = cd.nw * ((ppt + cd.nw - 1) / cd.nw) * 1024;
+    const int hbp = (((th + maxk - 1) * (W + maxk - 1) * 64) + 1023) / 1024 * 1024;
+    const int cap = cd.nw == 4 ? 80 * 1024 : 160 * 1024;
+    const int fixed = (cd.nw == 4 ? 1 : 2) * xb + NTM * hbp + B6_EB;
+    int best = 0, best_stages = 1 << 30;
+    for (int t = 9; t >= 2; --t) {
+      if (t * (nbmax / 16) > 40 || fixed + 2 * t * nbmax * 64 > cap) continue;
+      int stages = 0;
+      for (int g = 0; g < ngroups; ++g) stages += (ks[g] * ks[g] + t - 1) / t;
+      if (stages <= best_stages) { best_stages = stages; best = t; }
+    }
+    if (force_t >= 2 && force_t <= 9 && force_t * (nbmax / 16) <= 40 && fixed + 2 * force_t * nbmax * 64 <= cap) best = force_t;
+    if (!best) continue;
+    a.TH = th; a.tpi = H / th; a.xb_bytes = xb; a.hb_plane = hbp; a.T = best; a.wb_bytes = best * nbmax * 64; a.nxp = xb / 1024 / cd.nw;
+    plan.NW = cd.nw;
+    plan.lds = (size_t)fixed + 2 * (size_t)a.wb_bytes;
+    found = true;
+    break;
+  }
+  if (!found) return 1;
   auto recip = [](int d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)d + 1); };
   a.m_tpi = recip(a.tpi); a.m_T = recip(a.T);
-  plan.lds = 2 * (size_t)a.xb_bytes + (size_t)NTM * a.hb_plane + 2 * (size_t)a.wb_bytes + B6_EB;
   const long units = (long)N * a.tpi;
-  static const int gcap = getenv("HDMOE_B6_G") ? atoi(getenv("HDMOE_B6_G")) : 256;
+  static const int gcap_env = getenv("HDMOE_B6_G") ? atoi(getenv("HDMOE_B6_G")) : 0;
+  const long gcap = gcap_env > 0 ? gcap_env : (plan.NW == 4 ? 512 : 256);
   plan.G = (unsigned)(units < gcap ? units : gcap);
   plan.NTM = NTM; plan.NTB = NTB;
   a.stamps = (unsigned long long*)g_b6_stamps;
   static const int dbg = getenv("HDMOE_B6_DBG") ? atoi(getenv("HDMOE_B6_DBG")) : 0;
   a.dbg = dbg;
+  static const int desync = getenv("HDMOE_B6_DESYNC") ? atoi(getenv("HDMOE_B6_DESYNC")) : 0;
+  a.desync = desync;
   return 0;
 }
 
@@ -95,12 +116,17 @@ int blk6_launch(const B6Plan& plan, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     attr_set = true;
-#define B6_ATTR(M, B) (void)hipFuncSetAttribute((const void*)blk6_kernel<M, B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    B6_ATTR(1, 1); B6_ATTR(1, 2); B6_ATTR(2, 1); B6_ATTR(2, 2);
+#define B6_ATTR(W, M, B, L) (void)hipFuncSetAttribute((const void*)blk6_kernel<W, M, B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, L * 1024)
+    B6_ATTR(8, 1, 1, 160); B6_ATTR(8, 1, 2, 160); B6_ATTR(8, 2, 1, 160); B6_ATTR(8, 2, 2, 160);
+    B6_ATTR(4, 1, 1, 80); B6_ATTR(4, 1, 2, 80); B6_ATTR(4, 2, 1, 80); B6_ATTR(4, 2, 2, 80);
   }
-#define B6_LAUNCH(M, B) hipLaunchKernelGGL((blk6_kernel<M, B, MODE>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.a)
-  if (plan.NTM == 2) { if (plan.NTB == 2) B6_LAUNCH(2, 2); else B6_LAUNCH(2, 1); }
-  else { if (plan.NTB == 2) B6_LAUNCH(1, 2); else B6_LAUNCH(1, 1); }
+#define B6_LAUNCH(W, M, B) hipLaunchKernelGGL((blk6_kernel<W, M, B, MODE>), dim3(plan.G), dim3(64 * W), plan.lds, stream, plan.a)
+#define B6_GO(W)                                                                                  \
+  do {                                                                                            \
+    if (plan.NTM == 2) { if (plan.NTB == 2) B6_LAUNCH(W, 2, 2); else B6_LAUNCH(W, 2, 1); }       \
+    else { if (plan.NTB == 2) B6_LAUNCH(W, 1, 2); else B6_LAUNCH(W, 1, 1); }                     \
+  } while (0)
+  if (plan.NW == 4) B6_GO(4); else B6_GO(8);
   return hdmoe_launch_status();
 }
 
@@ -112,8 +138,8 @@ extern "C" {
 int hdmoe_blk6_debug_stamps(void* buf) { g_b6_stamps = buf; return HDMOE_OK; }
 
 /* Forward of Unet_block's main branch for all experts of a layer (reference models/model_components.py:240-253):
- *   u = conv(x, w1)                         [N][H][W][C]   (written: the backward needs the pre-activation)
- *   h = dropout_p(mp_silu(u * e[n][c]))     [N][H][W][C]   (written: conv_res2's weight gradient reads it)
+ *   u = conv(x, w1)                         [N][H][W][C]   (written: the backward needs the pre-activation; NULL: not stored)
+ *   h = dropout_p(mp_silu(u * e[n][c]))     [N][H][W][C]   (written: conv_res2's weight gradient reads it; NULL: not stored)
  *   y = alpha * conv(h, w2) + beta * res    [N][H][W][C]
  * x [N][H][W][Cin] bf16 is the block's (already mp_silu'd) input; w1 [g][tap][C][Cin], w2 [g][tap][C][C]: forward weight images of
  * hdmoe_wbank_prep / hdmoe_wprep_fwd (w?stride elements per expert); kh: per-expert square kernel size ("same" padding); e fp32 [N][C];
@@ -123,7 +149,7 @@ int hdmoe_unet_block_fwd(const void* x, const void* w1, const void* w2, void* u,
                          unsigned long long seed, const unsigned long long* seed_dev, float p, float alpha, float beta, const int* seg,
                          int ngroups, long w1stride, long w2stride, int N, int H, int W, int Cin, int C, const int* kh, int dtype,
                          hipStream_t stream) {
-  if (!x || !w1 || !w2 || !u || !h || !y || !e || N < 0 || p < 0.f || p >= 1.f) return HDMOE_EINVAL;
+  if (!x || !w1 || !w2 || !y || !e || N < 0 || p < 0.f || p >= 1.f) return HDMOE_EINVAL;       // (u, h may be NULL: inference, nothing saved for a backward)
   if (dtype != HDMOE_BF16) return 1;
   if (((uintptr_t)u | (uintptr_t)h) & 15) return 1;
   if (N == 0) return HDMOE_OK;

@@ -24,6 +24,7 @@ struct B6Args {
   int TH, tpi;                        // tile rows (TH * W = 256 output pixels), tiles per image
   int T;                              // taps per weight stage
   int xb_bytes, hb_plane, wb_bytes;   // one x-chunk buffer / one 32-channel plane of the intermediate / one weight stage buffer
+  int nxp;                            // x pieces every wave issues per chunk (xb_bytes / 1024 / waves)
   int xbytes, wabytes, wbbytes;       // buffer-descriptor extents
   unsigned m_tpi, m_T;                // 2^32 / d + 1 reciprocals
   int mode;                           // 0: FiLM forward, 1: FiLM backward
@@ -34,19 +35,25 @@ struct B6Args {
   const unsigned long long* seed_dev; unsigned seed_lo, seed_hi; float p;
   unsigned long long* stamps;         // development: s_memtime stamps of workgroup 0 ([wave][64] slots), or null
   int dbg;                            // development ablations: 1 no MFMA loops, 2 no DMA inside the loops, 4 no global stores, 8 no middle op
+  int desync;                         // 4-wave variant: how the two workgroups of a CU are kept out of phase (0 off, 1 priority by parity, 2 priority by grid half, 3 / 4: start delay)
 };
 
 struct B6Unit { int g, ks, n, ty0, rend; };     // (everything else follows from ks: kept out of the record, scalar registers are scarce here)
 struct B6Geo { int pd, ntaps, ntg, WXp, HX, HM, ppt, nblkA; };
 
-template <int NTM, int NTB, int MODE>
+// NW = 8: one 8-wave workgroup per CU, two x-chunk buffers.  NW = 4: 4-wave workgroups, TWO per CU (<= 80 KB of LDS each, one x-chunk
+// buffer): the phases of a unit -- conv A, middle op, conv B, stores -- are serial inside a workgroup, so a lone workgroup leaves the
+// matrix pipe idle during its middle op / epilogues and the VALU idle during its MFMA stages; two independent workgroups interleave.
+template <int NW, int NTM, int NTB, int MODE>
 DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int NW = 8;
+  constexpr bool XS = NW == 4;                  // single x buffer: the next chunk / unit is fetched once every wave is done with the current one
   constexpr int NBM = 32 * NTM, NBB = 32 * NTB;
   constexpr int PPTA = NBM / 16, PPTB = NBB / 16;
-  constexpr int NPW = 6;                        // x pieces per wave (<= 48 pieces of 16 pixels per chunk)
-  constexpr int NWP = 5;                        // weight pieces per wave per stage (T * NB / 16 <= 40)
+  constexpr int NPW = NW == 8 ? 6 : 9;          // x pieces per wave (<= 48 / <= 36 pieces of 16 pixels per chunk)
+  constexpr int NWP = 40 / NW;                  // weight pieces per wave per stage (T * NB / 16 <= 40)
+  constexpr int MBA = NW == 8 ? 2 : (NTM == 2 ? 2 : 3);   // pixel blocks per wave: conv A over <= 16 (NW = 8) / <= 12 or <= 8 (NW = 4) blocks ...
+  constexpr int MBB = 8 / NW;                   // ... conv B over the tile's 8 blocks (4-wave variant: 2 each, or 1 each on a 128-pixel tile)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +76,14 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
     }
   };
   stamp(1);
+  if (NW == 4) {
+    // Two workgroups share a CU.  Left alone they run in lockstep -- same program, same unit sizes: both in their MFMA stages, then both
+    // in their middle ops -- and nothing overlaps.  A priority difference breaks the tie: the favoured workgroup takes the matrix pipe,
+    // the other one falls half a unit behind and from then on computes while its partner stores, and vice versa.
+    const bool second = (a.desync == 1 || a.desync == 3) ? (bid & 1) : (bid >= (G >> 1));
+    if ((a.desync == 1 || a.desync == 2) && second) __builtin_amdgcn_s_setprio(1);
+    if ((a.desync == 3 || a.desync == 4) && second) { for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(100); }
+  }
   // ---- unit list (as conv6_body.h): groups in descending kernel size; a unit = one TH x W tile of one routed row
   const int oi_l = lane & 7;
   int v_g = 0, v_ks = 0;
@@ -115,30 +130,18 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   auto ppt_of = [&](int ks) { return ((a.W + ks - 1) * (a.TH + 2 * (ks - 1)) + 15) >> 4; };
 
   // ---- x pieces (16 pixels x 32 channels of one chunk) of the unit's (HX x WXp) input region; ~0 = padding (the DMA writes zeros)
-  unsigned hyx[NPW];
-  int hyx_ks = -1;
-  auto hyx_update = [&](const B6Unit& u) {
-    if (u.ks == hyx_ks) return;
-    hyx_ks = u.ks;
-    const int WXp = a.W + u.ks - 1, HX = a.TH + 2 * (u.ks - 1), ppt = (WXp * HX + 15) >> 4;
-    const int magic = (1 << 20) / WXp + 1;
-    const int npx = WXp * HX;
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-      const int pi = wave + NW * k;
-      const int px = 16 * pi + prow;
-      int hy = (int)(((unsigned)px * (unsigned)magic) >> 20);
-      if (hy * WXp > px) --hy;
-      const int hx = px - hy * WXp;
-      hyx[k] = (pi < ppt && px < npx) ? (unsigned)((hy << 8) | hx) : 0xFFFFFFFFu;
-    }
-  };
   const int ca2 = a.Ca * 2;
-  auto plan_piece = [&](const B6Unit& u, int k) -> unsigned {
-    const int hy = (int)(hyx[k] >> 8), hx = (int)(hyx[k] & 255u);
+  auto plan_piece = [&](const B6Unit& u, int k) -> unsigned {      // (only when a workgroup starts, or its next unit belongs to another expert)
+    const int WXp = a.W + u.ks - 1, HX = a.TH + 2 * (u.ks - 1), ppt = (WXp * HX + 15) >> 4;
+    const int pi = wave + NW * k;
+    const int px = 16 * pi + prow;
+    const int magic = (1 << 20) / WXp + 1;
+    int hy = (int)(((unsigned)px * (unsigned)magic) >> 20);
+    if (hy * WXp > px) --hy;
+    const int hx = px - hy * WXp;
     const int pd = (u.ks - 1) >> 1;
     const int iy = u.ty0 - 2 * pd + hy, ix = hx - pd;
-    const bool ok = hyx[k] != 0xFFFFFFFFu && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const bool ok = pi < ppt && px < WXp * HX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     return ok ? (unsigned)(((u.n * a.H + iy) * a.W + ix) * ca2 + csl) : 0xFFFFFFFFu;
   };
   auto issue_xpiece = [&](unsigned off, int k, int c, int xbo) {
@@ -186,16 +189,16 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   B6Unit cur, nu;
   decode(j, cur);
   nu = cur;
-  unsigned hoc[NPW], hon[NPW];
-  hyx_update(cur);
+  unsigned hoc[NPW];                                            // this wave's DMA source offsets of the unit whose x chunks are (still) to be fetched
   int jn = j + G;
   bool has_next = jn < total;
 
-  const int XB0 = 0, HB0 = 2 * a.xb_bytes, WB0 = HB0 + NTM * a.hb_plane, EB0 = WB0 + 2 * a.wb_bytes;     // EB: this unit's FiLM vector e[n][0 .. Cm)
+  const int XB0 = 0, HB0 = (XS ? 1 : 2) * a.xb_bytes, WB0 = HB0 + NTM * a.hb_plane, EB0 = WB0 + 2 * a.wb_bytes;     // EB: this unit's FiLM vector e[n][0 .. Cm)
   const int nchA = a.Ca >> 5;
   const int nblkB = a.Cb / NBB;
   const int wl = r * 64 + ((h << 4) ^ (((r >> 2) & 3) << 4));
   const int tws = a.W == 32 ? 5 : 4;
+  const int nblkT = (a.TH * a.W) >> 5;                          // 32-pixel blocks of the output tile (8, or 4)
 
   // zero the intermediate image once (its padding columns are never written; re-done when the kernel size -- the image's row pitch -- changes)
   auto zero_hb = [&]() {
@@ -205,30 +208,32 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   zero_hb();
   int hb_ks = cur.ks;
   B6Geo cg = geo_of(cur.ks);
+  // this wave's x pieces of one chunk: always a.nxp of them (pieces past the region are zero fills inside the buffer), so that the count of
+  // DMA instructions in flight behind a point is known for counted waits
+  auto issue_xchunk = [&](const unsigned (&off)[NPW], int c, int xbo) {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) if (k < a.nxp) issue_xpiece(off[k], k, c, xbo);
+  };
   // prologue: first weight stage of conv A, first x chunk
   {
     WNext w0{0, baseA(cur, 0, 0), wpieces(min(a.T, cg.ntaps), PPTA)};
     issue_wstage(w0, WB0);
-    const int nh = xpieces(cg.ppt);
 #pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-      hoc[k] = plan_piece(cur, k);
-      hon[k] = 0xFFFFFFFFu;
-      if (k < nh) issue_xpiece(hoc[k], k, 0, XB0);
-    }
+    for (int k = 0; k < NPW; ++k) hoc[k] = plan_piece(cur, k);
+    issue_xchunk(hoc, 0, XB0);
   }
   int par = 0, sp = 0;
 
   // ---- one weight stage of MFMAs: MB pixel blocks x NT 32-channel blocks, operands from the pixel image at `bufpx` and the stage buffer `wbuf`
   // (the tap cursor goes in and out BY VALUE, packed ky << 8 | kx: as reference parameters of this generic lambda the two counters were
   //  kept in scratch memory and every tap stored them back -- VMEM traffic inside the MFMA loop that the stage barriers then waited for)
-  auto mma_stage = [&](auto MBt, auto NTt, f32x16 (&acc)[2][2], const int (&P0)[2], int bufpx, int HWp, int ks, int cursor,
+  auto mma_stage = [&](auto MBt, auto NTt, f32x16 (&acc)[3][2], const int (&P0)[3], int bufpx, int HWp, int ks, int cursor,
                        const unsigned char* wbuf, int ntl, int bt, auto&& burst) -> int {
     constexpr int MB = decltype(MBt)::value, NT = decltype(NTt)::value, NB = 32 * NT;
     // Fragment lookahead in taps.  A wave with one or two MFMAs per k-step (1 x 1, 2 x 1, 1 x 2 tiles) issues a tap's MFMAs in 64-128
     // cycles but waits ~250 for the fragments of the next one: two taps ahead (three register sets) the LDS latency is covered; the 2 x 2
     // tile (8 MFMAs per tap, no registers to spare) relies on its SIMD partner instead.
-    constexpr int D = (MB * NT >= 4) ? 0 : (NTM == 1 ? 2 : 1);        // (the 64-channel variants have registers for one tap of lookahead only)
+    constexpr int D = (MB * NT >= 4) ? 0 : ((NW == 8 && NTM == 1) ? 2 : 1);   // (registers: the 64-channel and the 4-wave variants get one tap)
     if (a.dbg & 1) { burst(); return cursor; }
     int ky = cursor >> 8, kx = cursor & 255;
     bf16x8 fx[D + 1][2][MB], fw[D + 1][2][NT];
@@ -285,6 +290,25 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
   };
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  // s_waitcnt vmcnt(n) for a run-time n <= 12: everything but the n youngest VMEM operations of this wave has completed
+  auto wait_vm_all_but = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+  };
 
   bool first_unit = true;
   float e_reg = (wave == 0 && lane < a.Cm) ? a.e[(long)cur.n * a.Cm + lane] : 0.f;
@@ -298,26 +322,26 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
       hb_ks = cur.ks;
     }
     // =========================================== conv A over the (HM x W) region the second conv needs ===========================================
-    // this wave's blocks: wave and wave + 8 (32 pixels each; rows of 32, or pairs of rows of 16)
-    const int nvA = (wave + NW < cg.nblkA) ? 2 : 1;
-    int P0A[2], mrA[2], mcA[2];
+    // this wave's blocks: wave, wave + NW, ... (32 pixels each; rows of 32, or pairs of rows of 16)
+    const int nvA = min(MBA, (cg.nblkA - wave + NW - 1) / NW);
+    int P0A[3], mrA[3], mcA[3];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 3; ++m) {
       const int blk = min(wave + NW * m, cg.nblkA - 1);
       const int q = blk * 32 + r;
       mrA[m] = q >> tws; mcA[m] = q & (a.W - 1);
       P0A[m] = mrA[m] * cg.WXp + mcA[m];
     }
-    f32x16 acc[2][2];
+    f32x16 acc[3][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MBA; ++m)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[m][b] = (f32x16)(0.f);
+      for (int b = 0; b < NTM; ++b) acc[m][b] = (f32x16)(0.f);
 
     for (int c = 0; c < nchA; ++c) {
       const bool last_chunk = c == nchA - 1;
-      int hmode = 0, nh = 0;
-      if (!last_chunk) { hmode = 1; nh = xpieces(cg.ppt); }
+      int hmode = 0;
+      if (!last_chunk) hmode = 1;
       else if (has_next) {
         // Units are dealt round robin (j, j + G, ...): with G a multiple of the tiles per image the successor is the SAME tile of row
         // n + G / tpi -- same expert, kernel size and padding pattern unless that row belongs to the next expert: no decode, the DMA
@@ -327,17 +351,16 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
           nu = cur; nu.n = cur.n + dn;
           const unsigned step_b = (unsigned)(dn * a.H * a.W * ca2);
 #pragma unroll
-          for (int k = 0; k < NPW; ++k) hon[k] = hoc[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : hoc[k] + step_b;
+          for (int k = 0; k < NPW; ++k) hoc[k] = hoc[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : hoc[k] + step_b;
         } else {
           decode(jn, nu);
-          hyx_update(nu);
 #pragma unroll
-          for (int k = 0; k < NPW; ++k) hon[k] = plan_piece(nu, k);
-        }
-        hmode = 2; nh = xpieces(ppt_of(nu.ks));
+          for (int k = 0; k < NPW; ++k) hoc[k] = plan_piece(nu, k);
+        }                                                       // (the current unit's last chunk is in LDS or on its way: hoc now describes the successor)
+        hmode = 2;
         if (wave == 0 && lane < a.Cm) e_reg = a.e[(long)nu.n * a.Cm + lane];
       }
-      const int xbn = XB0 + (par ^ 1) * a.xb_bytes;
+      const int xbn = XS ? XB0 : XB0 + (par ^ 1) * a.xb_bytes;
       int cursor = 0;
       for (int tg = 0; tg < cg.ntg; ++tg) {
         const int t0 = tg * a.T;
@@ -350,29 +373,32 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
         if (tg + 1 < cg.ntg) wn = WNext{0, baseA(cur, c, t0 + a.T), wpieces(min(a.T, cg.ntaps - t0 - a.T), PPTA)};
         else if (!last_chunk) wn = WNext{0, baseA(cur, c + 1, 0), wpieces(min(a.T, cg.ntaps), PPTA)};
         else wn = WNext{1, baseB(cur, 0, 0, 0), wpieces(min(a.T, cg.ntaps), PPTB)};
-        const int nhs = tg == 0 ? nh : 0;
+        const bool xnow = !XS && tg == 0 && hmode != 0;         // two x buffers: the next chunk / unit rides on this chunk's first stage
         auto burst = [&]() {                                    // the next stage's weights, the next chunk's / unit's x pieces
           issue_wstage(wn, wbn);
-          if (a.dbg & 2) return;
-          if (hmode == 2) {
-#pragma unroll
-            for (int k = 0; k < NPW; ++k) if (k < nhs) issue_xpiece(hon[k], k, 0, xbn);
-          } else {
-#pragma unroll
-            for (int k = 0; k < NPW; ++k) if (k < nhs) issue_xpiece(hoc[k], k, c + 1, xbn);
-          }
+          if ((a.dbg & 2) || !xnow) return;
+          issue_xchunk(hoc, hmode == 2 ? 0 : c + 1, xbn);
         };
-        const int bt = min(wave >> 2, ntl - 1);                 // (waves 4-7 one tap later than their SIMD partners 0-3)
-        const int bufpx = (XB0 + par * a.xb_bytes) >> 6;
+        const int bt = min(NW == 8 ? wave >> 2 : wave & 1, ntl - 1);     // (SIMD partners / alternate waves one tap apart)
+        const int bufpx = (XS ? XB0 : XB0 + par * a.xb_bytes) >> 6;
         const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
-        if (nvA == 2) cursor = mma_stage(I2{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
+        if (MBA >= 3 && nvA >= 3) cursor = mma_stage(I3{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
+        else if (nvA == 2) cursor = mma_stage(I2{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
         else cursor = mma_stage(I1{}, std::integral_constant<int, NTM>{}, acc, P0A, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
         sp ^= 1;
+      }
+      if (XS) {
+        // one x buffer: every wave is done with the chunk -> fetch the next one (this unit's, exposed: the other workgroup of the CU covers
+        // it; or the next unit's, which lands under the middle op and conv B)
+        stage_barrier(false);
+        if (hmode != 0 && !(a.dbg & 2)) issue_xchunk(hoc, hmode == 2 ? 0 : c + 1, XB0);
       }
       par ^= 1;
     }
     stamp(5);
-    drain_dma();                                              // conv B's first weight stage (issued beside the last stage above) has landed
+    // conv B's first weight stage (issued beside the last stage above) has landed; with one x buffer the next unit's a.nxp x pieces were
+    // issued after it and stay in flight
+    if (XS && has_next && !(a.dbg & 2)) wait_vm_all_but(a.nxp); else drain_dma();
     stamp(6);
     // ---- middle op on conv A's accumulators -> intermediate image in LDS (every position of the region: activation, or 0 outside the image)
     {
@@ -382,7 +408,7 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
       bf16* HM = (bf16*)a.hmid;
       const int WMp = cg.WXp;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < MBA; ++m) {
         if (m < nvA && !(a.dbg & 8)) {
           const int mr = mrA[m], mc = mcA[m];
           const int iy = cur.ty0 - cg.pd + mr;
@@ -416,7 +442,7 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
                   philox((uint32_t)(q0 + 1), (uint32_t)((q0 + 1) >> 32), seed_lo, seed_hi, r4 + 4);
                 }
                 if constexpr (MODE == 0) {
-                  if (owned && !(a.dbg & 4)) *reinterpret_cast<uint4*>(U + eo) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                  if (owned && U && !(a.dbg & 4)) *reinterpret_cast<uint4*>(U + eo) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 #pragma unroll
                   for (int j2 = 0; j2 < 4; ++j2) {
                     const bf2 yv = __builtin_bit_cast(bf2, pk[j2]);
@@ -428,7 +454,7 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
                     }
                     ho[j2] = __builtin_bit_cast(unsigned, (bf2){(bf16)f0, (bf16)f1});
                   }
-                  if (owned && !(a.dbg & 4)) *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+                  if (owned && HM && !(a.dbg & 4)) *reinterpret_cast<uint4*>(HM + eo) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
                 } else {
                   // FiLM / mp_silu / dropout backward on the bf16-rounded d(activation): du = g * silu'(u e) * e, de += g * silu'(u e) * u
                   const uint4 uq = *reinterpret_cast<const uint4*>(U + eo);
@@ -472,28 +498,39 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
     stamp(7);
     // =========================================== conv B over the tile, intermediate read from LDS ===========================================
     {
-      const int q = wave * 32 + r;
-      const int orow = q >> tws, oc = q & (a.W - 1);
-      const int P0B[2] = {orow * cg.WXp + oc, 0};
-      const int yy = cur.ty0 + orow;
-      for (int nb = 0; nb < nblkB; ++nb) {
-        f32x16 accb[2][2];
+      // this wave's blocks of the output tile: wave, wave + NW (4-wave variant on a 256-pixel tile)
+      const int nvB = min(MBB, (nblkT - wave + NW - 1) / NW);
+      int P0B[3], orowB[MBB], ocB[MBB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) accb[0][b] = (f32x16)(0.f);
+      for (int m = 0; m < 3; ++m) {
+        const int q = min(wave + NW * m, nblkT - 1) * 32 + r;
+        if (m < MBB) { orowB[m] = q >> tws; ocB[m] = q & (a.W - 1); }
+        P0B[m] = (q >> tws) * cg.WXp + (q & (a.W - 1));
+      }
+      for (int nb = 0; nb < nblkB; ++nb) {
+        f32x16 accb[3][2];
+#pragma unroll
+        for (int m = 0; m < MBB; ++m)
+#pragma unroll
+          for (int b = 0; b < NTB; ++b) accb[m][b] = (f32x16)(0.f);
         // the residual's quads for the epilogue: loaded now, they arrive while the taps below run
         const bf16* R = (const bf16*)a.res;
-        const long pix = (((long)cur.n * a.H + yy) * a.W + oc) * a.Cb + nb * NBB;
+        long pixB[MBB];
+#pragma unroll
+        for (int m = 0; m < MBB; ++m) pixB[m] = (((long)cur.n * a.H + cur.ty0 + orowB[m]) * a.W + ocB[m]) * a.Cb + nb * NBB;
         constexpr bool RPF = NTB == 1;                        // (the 64-channel variant has no registers left for it: it loads in the epilogue)
-        bf16x4 rq[NTB][2][2];
+        bf16x4 rq[MBB][NTB][2][2];
         if (RPF && R) {
 #pragma unroll
-          for (int b = 0; b < NTB; ++b)
+          for (int m = 0; m < MBB; ++m)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              const long o0 = pix + 32 * b + 16 * p + 4 * h;
-              rq[b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
-              rq[b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
-            }
+            for (int b = 0; b < NTB; ++b)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) {
+                const long o0 = pixB[m] + 32 * b + 16 * p + 4 * h;
+                rq[m][b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
+                rq[m][b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+              }
         }
         for (int c = 0; c < NTM; ++c) {
           int cursor = 0;
@@ -510,10 +547,11 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
             else if (nb + 1 < nblkB) wn = WNext{1, baseB(cur, nb + 1, 0, 0), wpieces(min(a.T, cg.ntaps), PPTB)};
             else if (has_next) wn = WNext{0, baseA(nu, 0, 0), wpieces(min(a.T, nu.ks * nu.ks), PPTA)};
             auto burst = [&]() { issue_wstage(wn, wbn); };
-            const int bt = min(wave >> 2, ntl - 1);
+            const int bt = min(NW == 8 ? wave >> 2 : wave & 1, ntl - 1);
             const int bufpx = (HB0 + c * a.hb_plane) >> 6;
             const unsigned char* wbuf = lds + WB0 + sp * a.wb_bytes;
-            cursor = mma_stage(I1{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
+            if (MBB == 2 && nvB == 2) cursor = mma_stage(I2{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
+            else cursor = mma_stage(I1{}, std::integral_constant<int, NTB>{}, accb, P0B, bufpx, cg.WXp, cur.ks, cursor, wbuf, ntl, bt, burst);
             sp ^= 1;
           }
         }
@@ -523,29 +561,34 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
         // epilogue: y = alpha * acc + beta * res (fp32, one rounding), 16-byte stores
         bf16* Y = (bf16*)a.y;
 #pragma unroll
-        for (int b = 0; b < NTB; ++b)
+        for (int m = 0; m < MBB; ++m) {
+          if (m < nvB) {
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            float v[8];
+            for (int b = 0; b < NTB; ++b)
 #pragma unroll
-            for (int q2 = 0; q2 < 8; ++q2) v[q2] = a.alpha * accb[0][b][8 * p + q2];
-            if (R) {
-              if (!RPF) {
-                const long o0 = pix + 32 * b + 16 * p + 4 * h;
-                rq[b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
-                rq[b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+              for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2) v[q2] = a.alpha * accb[m][b][8 * p + q2];
+                if (R) {
+                  if (!RPF) {
+                    const long o0 = pixB[m] + 32 * b + 16 * p + 4 * h;
+                    rq[m][b][p][0] = *reinterpret_cast<const bf16x4*>(R + o0);
+                    rq[m][b][p][1] = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+                  }
+#pragma unroll
+                  for (int q2 = 0; q2 < 4; ++q2) { v[q2] += a.beta * (float)rq[m][b][p][0][q2]; v[4 + q2] += a.beta * (float)rq[m][b][p][1][q2]; }
+                }
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                const unsigned A0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[0], (bf16)v[1]}), A1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[2], (bf16)v[3]});
+                const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+                if (!(a.dbg & 4)) *reinterpret_cast<uint4*>(Y + pixB[m] + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
               }
-#pragma unroll
-              for (int q2 = 0; q2 < 4; ++q2) { v[q2] += a.beta * (float)rq[b][p][0][q2]; v[4 + q2] += a.beta * (float)rq[b][p][1][q2]; }
-            }
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-            const unsigned A0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[0], (bf16)v[1]}), A1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[2], (bf16)v[3]});
-            const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
-            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
-            if (!(a.dbg & 4)) *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
+        }
       }
     }
     stamp(12);
@@ -553,8 +596,6 @@ DEVI void blk6_body(const B6Args& a, const int bid, const int G) {
     first_unit = false;
     cur = nu;
     if (cg.pd != ((cur.ks - 1) >> 1)) cg = geo_of(cur.ks);
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) hoc[k] = hon[k];
     jn += G;
     has_next = jn < total;
   }

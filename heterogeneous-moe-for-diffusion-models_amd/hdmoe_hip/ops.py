@@ -1067,9 +1067,11 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     p = float(p) if training else 0.0
     e32 = _f32(emb)
     seed = _next_seed() if p > 0.0 else 0
-    u = torch.empty((N, H, W, C), dtype=h.dtype, device=h.device)
-    hb = torch.empty_like(u)
-    y = torch.empty_like(u)
+    y = torch.empty((N, H, W, C), dtype=h.dtype, device=h.device)
+    need_bwd = torch.is_grad_enabled() and (h.requires_grad or emb.requires_grad or any(w.requires_grad for w in w1s + w2s))
+    # (inference: the pre-activation and the activation are not written at all -- two of the launch's three output streams)
+    u = torch.empty_like(y) if need_bwd else None
+    hb = torch.empty_like(y) if need_bwd else None
     if _timed("fused", dict(name="blk6_kernel (fwd)", dtype="bfloat16", seg=seg, N=N, HW=H * W, O=C, I=Cin + C, taps=[k * k for k in ent1.khs], mult=1.0),
               "hdmoe_unet_block_fwd", h, ent1.wf, ent2.wf, u, hb, y, res, e32, seed, step_counter(h.device), p, float(alpha), float(beta), seg,
               len(w1s), ent1.wstride, ent2.wstride, N, H, W, Cin, C, ent1.khs, _dt(h)) != 0:
@@ -1077,6 +1079,8 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
             _seed_state["ctr"] -= 1                            # nothing was launched: the unfused path draws this salt itself
         return None
     STATS["blk"] += 1
+    if not need_bwd:
+        return y
     ws1 = w1s if seg is not None else w1s[0]
     ws2 = w2s if seg is not None else w2s[0]
     try:

@@ -1,0 +1,7 @@
+tag=$1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o s --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 10 --warmup 3 > $R/gpurun_out/${tag}_stats.log 2>&1
+python3 $R/tools/kernel_hist.py $R/gpurun_out/${tag}_stats/s_kernel_trace.csv 10 90 > $R/gpurun_out/${tag}_kernel_hist.txt
+rm -f $R/gpurun_out/${tag}_stats/s_kernel_trace.csv
+head -100 $R/gpurun_out/${tag}_kernel_hist.txt
