@@ -121,7 +121,13 @@ def roofline_leg(step_fn, n_steps):
     agg = {}
     shapes = {}
     per_shape = {}
+    attn = {}
     for kind, info, s, e in rec:
+        if kind == "attn":                                   # attention cores: exp-issue bound, not a GEMM roofline (reported separately)
+            key = f"{info['dir']} B={info['B']} Sq={info['Sq']} Skv={info['Skv']} H={info['H']} D={info['D']}"
+            t = attn.setdefault(key, dict(info=info, ms=[]))
+            t["ms"].append(max(s.elapsed_time(e) - overhead, 0.001))
+            continue
         name = info["name"] if kind == "fused" else (info["fwd_name"] if kind == "conv_fwd" else info["wgrad_name"])
         sk = f"{name} N={info['N']} HW={info['HW']} O={info['O']} I={info['I']} taps={info['taps']}"
         per_shape.setdefault(sk, []).append((name, info, max(s.elapsed_time(e) - overhead, 0.001)))
@@ -136,6 +142,21 @@ def roofline_leg(step_fn, n_steps):
             a["ms"] += d
             a["flops"] += conv_flops(info) * info.get("mult", 1.0)     # fused launches: dgrad + wgrad (x 2), conv_res1 + conv_res2 (I = Cin + C)
             a["n"] += 1
+    # v_exp_f32 issues at 8 cycles per wave-instruction (MI355X_MICROARCH.md): 1024 SIMDs x 64 lanes / 8 cycles x 2.4 GHz exps per second.
+    # The forward evaluates one exp per (query, key, head) pair; the backward recomputes the probabilities in both of its kernels (dq; dk + dv).
+    exp_peak = 1024 * 64 / 8 * 2.4e9
+    rep = []
+    for key, t in sorted(attn.items(), key=lambda kv: -sum(kv[1]["ms"])):
+        i = t["info"]
+        ms = sorted(t["ms"])[len(t["ms"]) // 2]
+        pairs = float(i["B"]) * i["H"] * i["Sq"] * i["Skv"]
+        exps = pairs * (1 if i["dir"] == "fwd" else 2)
+        E = i["H"] * i["D"]
+        hbm = i["B"] * E * i["esz"] * ((2 * i["Sq"] + 2 * i["Skv"]) if i["dir"] == "fwd" else (5 * i["Sq"] + 4 * i["Skv"]))
+        rep.append(dict(shape=key, median_ms=round(ms, 4), launches_per_step=len(t["ms"]) / n_steps, exps_per_s=round(exps / (ms * 1e-3), 1),
+                        exp_issue_bound_per_s=exp_peak, frac_of_exp_bound=round(exps / (ms * 1e-3) / exp_peak, 4),
+                        hbm_floor_us=round(hbm / 6.3e12 * 1e6, 2), frac_of_hbm_floor=round(hbm / 6.3e12 / (ms * 1e-3), 4)))
+    roofline_leg.attention = rep[:4] or None
     if not agg:
         return None, {}
     def roof_of(name, a):
@@ -170,7 +191,7 @@ def roofline_leg(step_fn, n_steps):
                 method="HIP events around each launch on the launch stream, a spacer launch in front keeps host enqueue gaps out and the event-pair overhead measured on a trivial launch is subtracted; see profiles/", event_overhead_us=round(1e3 * overhead, 2)), table
 
 
-def cpu_baseline(cfg_id, kw, module, seconds=12.0):
+def cpu_baseline(cfg_id, kw, module, seconds=9.0):
     """The CPU oracle (port of the reference algorithm) timed on the host cores on a bounded sample: B = 8 samples per
     step, TRAIN-mode (dropout 0.2, logit noise zeta 0.1) fwd + EDM loss + bwd, as many steps as fit in ~`seconds`."""
     from oracle import hdmoe_oracle as O
@@ -214,9 +235,58 @@ def cpu_baseline(cfg_id, kw, module, seconds=12.0):
         print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
         if len(times) >= 40:
             break
-    O.TRAIN.update(on=False)
     med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    # second point (n = 8 threads as well): a few more steps on 8 threads
+    med8 = None
+    if cores != 8:
+        torch.set_num_threads(8)
+        t8 = []
+        t_end = time.time() + 5.0
+        while time.time() < t_end or len(t8) < 3:
+            t0 = time.time()
+            out = O.preconditioned_hdmoem(P, cfg, module, inp["x"], inp["sigma"], inp["text"], inp["um"], inp["vm"], return_log_var=True, **inp["extra"])
+            O.edm_loss(out, inp["x0"], kw["num_experts"], lc["unet_bal"], lc["vit_bal"], lc["z_bal"])["loss"].backward()
+            for v in P.values():
+                v.grad = None
+            t8.append(time.time() - t0)
+        med8 = sorted(t8[1:])[len(t8[1:]) // 2]
+        torch.set_num_threads(cores)
+    cpu_baseline.med8 = med8
+    O.TRAIN.update(on=False)
     return med, B, cores, len(times)
+
+
+def sampler_leg(device, B=128, N=40):
+    """BASELINE configs[4] on this GPU's share of the batch (1024 images over 8 GPUs = 128 per GPU): EDM_Sampler, 2nd-order Heun, N = 40
+    solver steps = 79 denoiser evaluations, 8 heterogeneous experts top-2, 4x64x64 latents, bf16, eval, the evaluation replayed as a
+    hipGraph.  Independent replicas: no collective.  Returns a record for the bench line."""
+    import hdmoe_hip
+    import configs as C
+    from EDM_sampler import EDM_Sampler
+    from models import model_config2
+    hdmoe_hip.set_compute_dtype(torch.bfloat16)
+    kw = C.model_kwargs(**C.BASELINE_CONFIGS[4]["over"])
+    torch.manual_seed(0)
+    model = model_config2.preconditioned_HDMOEM(**kw).to(device).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("out_gain"):
+                p.fill_(0.5)
+    g = torch.Generator(device=device).manual_seed(7)
+    noise = torch.randn(B, 4, 64, 64, device=device, generator=g)
+    text = torch.randn(B, 77, kw["text_emb_dim"], device=device, generator=g)
+    smp = EDM_Sampler(model, Guide_net=model, guidance=1.0, num_solve_steps=N, use_graph=True)
+    with torch.no_grad():
+        smp.sample(noise=noise, text_emb=text, transition_mean=-1.2, softness=1.2)     # warm-up + capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = smp.sample(noise=noise, text_emb=text, transition_mean=-1.2, softness=1.2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out).all())
+    return dict(metric="imgs/sec, EDM_Sampler (BASELINE configs[4] per-GPU share)", value=round(B / dt, 2) if ok else None, batch=B, solver_steps=N,
+                denoiser_evals=2 * N - 1, ms_per_eval=round(1e3 * dt / (2 * N - 1), 3), latents="4x64x64", experts="8 heterogeneous (3x3 / 5x5 / 7x7), top-2",
+                dtype="bf16", launch="hipGraph replay of the denoiser evaluation", finite=ok)
 
 
 def main():
@@ -228,6 +298,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the EDM_Sampler leg (BASELINE configs[4] shape, ~4 s)")
     ap.add_argument("--dump-kernels", default="", help="write the per-kernel table of the roofline leg to this JSON file")
     ap.add_argument("--single-graph", action="store_true", help="capture the step as ONE hipGraph instead of the seven staged graphs (A/B)")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: synchronize after every step (the host never runs ahead of the GPU)")
@@ -296,6 +367,7 @@ def main():
         return {"loss": fwd_bwd()}
 
     step = eager_step
+    graphed = None
     if not args.no_graph:
         # the step is ~2.4k launches: replay it as one hipGraph (fwd + loss + bwd + weight-gradient finish); the gradient
         # all-reduce stays outside the graph and runs right after the replay
@@ -401,7 +473,10 @@ def main():
         print(f"[bench] masked leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
     roof, table = (None, {})
     cpu = None
+    launch_desc = "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)")
     roof_unfused = None
+    attention_rep = None
+    sampler_rec = None
     if rank == 0:
         if not args.no_roofline:
             # per-launch events need eager launches; rank-local (no collective).  Leg 1: the launches of the REPLAYED step (weight-bank
@@ -410,6 +485,7 @@ def main():
             ops.PROFILE_FUSED = True
             roof, table = roofline_leg(local_step, 3)
             expert_in_step = getattr(roofline_leg, "expert", None)
+            attention_rep = getattr(roofline_leg, "attention", None)
             ops.PROFILE_FUSED = False
             roof_unfused, table_u = roofline_leg(local_step, 3)
             expert_unfused = getattr(roofline_leg, "expert", None)
@@ -419,12 +495,25 @@ def main():
             if args.dump_kernels:
                 with open(args.dump_kernels, "w") as f:
                     json.dump({"in_step_launches": table, "unfused_launches": table_u}, f, indent=1)
+        if world == 1 and not args.no_sampler and args.config == 2:
+            try:
+                graphed = None                                # (release the training step's graphs / pools first)
+                gc.collect()
+                torch.cuda.empty_cache()
+                sampler_rec = sampler_leg(device)
+            except Exception as exc:                          # a reported extra, never a reason to lose the headline line
+                print(f"[bench] sampler leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+                sampler_rec = None
+            hdmoe_hip.set_compute_dtype(torch.bfloat16 if bc["dtype"] == "bf16" else torch.float32)
         if world == 1 and not args.no_cpu_baseline:
             med, cb, cores, nst = cpu_baseline(args.config, kw, bc["module"])
             # metric unit: steps of B samples per second -> a CPU step of cb samples counts as cb/B of a bench step
             cpu = dict(value=round((cb / med) / B, 5), unit="denoise-steps/sec", cores=cores, kind="port",
                        sample=f"CPU oracle, fp32, train-mode (dropout, logit noise) fwd+loss+bwd on B={cb} samples/step, {cores} threads, median of {nst - 1} steps "
-                              f"({med:.2f} s/step = {cb / med:.2f} samples/s), scaled to the bench's {B}-sample step")
+                              f"({med:.2f} s/step = {cb / med:.2f} samples/s), scaled to the bench's {B}-sample step"
+                              + (f"; on 8 threads {cpu_baseline.med8:.2f} s/step" if getattr(cpu_baseline, "med8", None) else ""))
+            if getattr(cpu_baseline, "med8", None):
+                cpu["value_8_threads"] = round((cb / cpu_baseline.med8) / B, 5)
     if multi:
         dist.barrier()
     if rank == 0:
@@ -441,11 +530,12 @@ def main():
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none",
                        "step": "fwd + EDM_LOSS + bwd"
-                       + (" + RCCL grad all-reduce" if multi else ""), "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)"), "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
+                       + (" + RCCL grad all-reduce" if multi else ""), "launch": launch_desc, "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "loss_ok": loss_ok, "grads_equal_across_ranks": grads_equal, "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
                                 + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
-            "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "cpu_baseline": cpu,
+            "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "attention": attention_rep, "cpu_baseline": cpu,
+            "sampler": sampler_rec,
         }
         # value = whole-job throughput: every rank runs one B-sample step per step time (weak scaling) => world / t steps/s
         print(json.dumps(line), flush=True)

@@ -1933,7 +1933,8 @@ class _AttnFn(torch.autograd.Function):
             Sb = bias.shape[-1]
         out = torch.empty_like(q)
         lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-        call("hdmoe_attn_fwd", out, lse, q, k, v, bias, B, Sq, Skv, H, D, Sb, _dt(q))
+        _timed("attn", dict(dir="fwd", B=B, Sq=Sq, Skv=Skv, H=H, D=D, esz=q.element_size(), bias=bias is not None),
+               "hdmoe_attn_fwd", out, lse, q, k, v, bias, B, Sq, Skv, H, D, Sb, _dt(q))
         ctx.save_for_backward(q, k, v, bias, out, lse)
         ctx.H = H
         return out
@@ -1955,7 +1956,8 @@ class _AttnFn(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 direct = _direct(bias)
                 dbias = bias.grad if direct else torch.zeros_like(bias)
-        call("hdmoe_attn_bwd", dq, dk, dv, dbias, delta, g, out, q, k, v, lse, bias, B, Sq, Skv, H, E // H, Sb, _dt(q))
+        _timed("attn", dict(dir="bwd", B=B, Sq=Sq, Skv=Skv, H=H, D=E // H, esz=q.element_size(), bias=bias is not None),
+               "hdmoe_attn_bwd", dq, dk, dv, dbias, delta, g, out, q, k, v, lse, bias, B, Sq, Skv, H, E // H, Sb, _dt(q))
         return dq, dk, dv, (None if direct else dbias), None
 
 
