@@ -214,7 +214,11 @@ __global__ void attn_dbias_kernel(float* dbias, const T* dout, const T* q, const
 // the A operand (V^T, or K^T / Q^T / dO^T in the backward kernels) is staged in LDS in exactly that slot order (kslot()), so
 // no cross-lane movement is needed.  Row 4 of the padded V^T tile is all ones: O^T row 4 accumulates the softmax denominator
 // on the matrix pipe for free.  One workgroup = one 32-row block x all heads (wave w = head w), so K/V rows are loaded whole.
-constexpr int MK = 128;                                      // rows staged per barrier
+#ifndef HDMOE_ATTN_MK
+#define HDMOE_ATTN_MK 64
+#endif
+constexpr int MK = HDMOE_ATTN_MK;                            // rows staged per barrier (a multiple of 64)
+constexpr int MKR = MK / 64;                                 // 8-byte pieces of a staged tensor per thread
 DEVI f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 DEVI bf16x8 pack8(const f32x16& v, int s) {
   bf16x8 o;
@@ -234,10 +238,10 @@ DEVI bf16x8 head_frag(const bf16* row, bool valid) {
 // LDS image of a staged [rows][E] bf16 tensor: per head MK + 1 rows of 16 bytes, [x0 x1 x2 x3 e4 0 0 0] (e4 = 1 for V in the
 // forward kernel, else 0); row MK is all zeros.  Consecutive threads take consecutive heads of one row: whole global rows,
 // and the 16-byte LDS writes of the 8 heads land 2064 B apart = on disjoint bank quads (conflict-free).
-struct StageRegs { uint2 v[2]; };
+struct StageRegs { uint2 v[MKR]; };
 DEVI void stage_load(StageRegs& rg, const bf16* src, long row0, int nrows_valid, int H, int tid, int nthr) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MKR; ++i) {
     const int idx = tid + i * nthr;
     const int rr = idx / H, hd = idx - rr * H;
     uint2 t = make_uint2(0, 0);
@@ -247,7 +251,7 @@ DEVI void stage_load(StageRegs& rg, const bf16* src, long row0, int nrows_valid,
 }
 DEVI void stage_write(const StageRegs& rg, bf16* rowL, unsigned e4, int H, int tid, int nthr) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MKR; ++i) {
     const int idx = tid + i * nthr;
     const int rr = idx / H, hd = idx - rr * H;
     *reinterpret_cast<uint4*>(rowL + ((long)hd * (MK + 1) + rr) * 8) = make_uint4(rg.v[i].x, rg.v[i].y, e4, 0);
@@ -423,10 +427,10 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(bf16* dk, bf1
   const float* pd = sd + (long)h * MK + 4 * hh;
   f32x16 ak = (f32x16)(0.f), av = (f32x16)(0.f);
   StageRegs rq, rd;
-  float rl[2], rdl[2];
+  float rl[MKR], rdl[MKR];
   auto load_ld = [&](int i0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MKR; ++i) {
       const int idx = tid + i * nthr;
       const int rr = idx / H, hd = idx - rr * H;
       const bool ok = i0 + rr < Sq;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(bf16* dk, bf1
     stage_write(rq, rowQ, 0u, H, tid, nthr);
     stage_write(rd, rowD, 0u, H, tid, nthr);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MKR; ++i) {
       const int idx = tid + i * nthr;
       const int rr = idx / H, hd = idx - rr * H;
       sl[(long)hd * MK + rr] = rl[i];
@@ -493,12 +497,22 @@ static inline bool attn_mfma_ok(int H, const void* a, const void* b2, const void
   return !off && H >= 1 && H <= 8 && (((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 7) == 0;
 }
 
+static void attn_mfma_attrs() {                              // (the staged images exceed the 64 KB default with MK = 256)
+  static bool done = false;
+  if (done) return;
+  done = true;
+  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <typename T, int D>
 int attn_fwd_launch(void* out, float* lse, const void* q, const void* k, const void* v, const float* bias, int B, int Sq, int Skv,
                     int H, int Sb, hipStream_t st) {
   if constexpr (sizeof(T) == 2 && D == 4) {
     if (!bias && attn_mfma_ok(H, out, q, k, v)) {
       const size_t lds = (size_t)H * 2 * (MK + 1) * 16;
+      attn_mfma_attrs();
       hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds, st, (bf16*)out, lse, (const bf16*)q, (const bf16*)k,
                          (const bf16*)v, Sq, Skv, H, 1.4426950408889634f / sqrtf((float)D));
       return hdmoe_launch_status();
@@ -521,6 +535,7 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
       const float c = scale * 1.4426950408889634f;
       const size_t lds_q = (size_t)H * 2 * (MK + 1) * 16;
       const size_t lds_kv = (size_t)H * (2 * (MK + 1) * 16 + 2 * MK * 4);
+      attn_mfma_attrs();
       hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds_q, st, (bf16*)dq, delta, (const bf16*)dout,
                          (const bf16*)out, (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, Sq, Skv, H, scale, c);
       hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(Skv, 32), B), dim3(64 * H), lds_kv, st, (bf16*)dk, (bf16*)dv, (const bf16*)dout,
