@@ -205,20 +205,42 @@ __global__ void attn_dbias_kernel(float* dbias, const T* dout, const T* q, const
 // =====================================================================================================================
 // MFMA path: bf16, D = 4, no positional bias (the fusion cross-attention S = 1024 and the text cross-attention S_kv = 77).
 // The one-row-per-thread kernels above spend ~15 VALU instructions per (q, k) pair (4 cycles each on a wave64); here the
-// three contractions of a 32 x 32 tile run on the matrix pipe with the head dim zero-padded 4 -> 16 (75 % of each MFMA is
-// padding, still ~8x cheaper than the VALU form) and only the softmax arithmetic stays on the vector pipe.
+// three contractions of a 32 x 32 tile run on the matrix pipe with the head dim zero-padded 4 -> 16 and only exp2 and the
+// bf16 conversion of the probabilities stay on the vector pipe, which is the bound (v_exp_f32 issues every 8 cycles):
 //   S^T[k][q]  = K[k][:] . Q[q][:]            A = K rows (LDS),        B = Q (registers, fixed per wave)
 //   O^T[d][q] += V^T[d][k] * P^T[k][q]        A = V^T (LDS, permuted), B = P straight from the S^T accumulator registers
 // An accumulator lane (c, hh) holds column q = c and rows k = (reg&3) + 8(reg>>2) + 4hh, i.e. for the 16-deep slice s of the
 // second product its registers 8s..8s+7 ARE a B-operand fragment if K-slot (hh, j) is defined as k = 16s + (j&3) + 8(j>>2) + 4hh;
-// the A operand (V^T, or K^T / Q^T / dO^T in the backward kernels) is staged in LDS in exactly that slot order (kslot()), so
-// no cross-lane movement is needed.  Row 4 of the padded V^T tile is all ones: O^T row 4 accumulates the softmax denominator
-// on the matrix pipe for free.  One workgroup = one 32-row block x all heads (wave w = head w), so K/V rows are loaded whole.
-#ifndef HDMOE_ATTN_MK
-#define HDMOE_ATTN_MK 64
+// the A operand (V^T, or K^T / Q^T / dO^T in the backward kernels) comes out of LDS in exactly that slot order through the
+// transposing read, so no cross-lane movement is needed.  Row 4 of the V^T tile is all ones: O^T row 4 accumulates the softmax
+// denominator on the matrix pipe for free.
+//
+// The 12 padding slots of the first product carry the softmax's scalar arithmetic (round 3; before, each score cost a v_fma for
+// the scale and the shift, the online maximum 15 v_max + a cross-lane step per tile, and the backward a v_sub per score):
+//   slots 0-3   K side k_d        Q side hi(c * q_d)        c = log2(e) / sqrt(D): the product is the score in log2 units,
+//   slots 4-7   K side k_d        Q side lo(c * q_d)        hi + lo = 16 significant bits of c * q_d
+//   slots 8-10  K side 1          Q side -shift (a 1-3 term bf16 expansion)
+// so the accumulator IS  c * q.k - shift  and exp2 applies to it directly.  Forward: shift = the row maximum over the FIRST key tile,
+// rounded to bf16 (any shift gives the same softmax; lse = shift + log2(sum)); if a later key beats it by more than 2^127 -- or all
+// of them fall below 2^-126 of it -- the sums come out non-finite or zero, which the wave detects at the end of the head and then
+// repeats the sweep with the online maximum (`attn_fwd_sweep<false>`), so the result never depends on the heuristic.  Backward:
+// shift = the saved lse (p = exp2(S') exactly as the forward normalised it), and the dP product carries -delta the same way.
+//
+// Work split (round 3): a workgroup = 8 waves = 8 consecutive 32-row blocks of one sample; the heads are taken ONE AFTER THE OTHER and
+// for each head the whole other side (up to ATT_HS = 1024 rows of it) is staged in LDS as the raw 8-byte rows [x0 x1 x2 x3] --
+// double-buffered, so a head costs one barrier and the 32-tile sweep of a wave has none.  Before, a workgroup was one 32-row block x
+// 8 heads with a stage of 64 rows of all heads between two barriers: the barriers (cooperative whole-row loads) or, with wave-private
+// staging, the 8-byte loads 64 B apart (one L1 line pass per lane) cost 220 of the forward kernel's 350 us; staging per head moves
+// the same strided loads but 8x fewer of them, off the sweep.  What the 16-byte padded rows of the old image supplied -- the copy of
+// k for the hi / lo pair, the 1 of V's fifth column, zeros -- now comes from registers (a duplicated 8-byte read) and from a constant
+// 256-byte block the lanes of the transposing read that address columns 4..15 point to instead of the row.
+#ifndef HDMOE_ATTN_DBG
+#define HDMOE_ATTN_DBG 0
 #endif
-constexpr int MK = HDMOE_ATTN_MK;                            // rows staged per barrier (a multiple of 64)
-constexpr int MKR = MK / 64;                                 // 8-byte pieces of a staged tensor per thread
+constexpr int ATT_HS = 1024;                                 // rows of the streamed side staged per head image
+constexpr int ATT_IMG = ATT_HS * 8;                          // bytes of one raw head image
+constexpr int ATT_CONST = 1024;                              // constant block, period 64 B: 8-byte word 0 = [1 0 0 0], word 2 = [1 1 1 0], else zeros
+constexpr int CB_ONE = 0, CB_ZERO = 8, CB_ONE3 = 16;
 DEVI f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 DEVI bf16x8 pack8(const f32x16& v, int s) {
   bf16x8 o;
@@ -226,7 +248,10 @@ DEVI bf16x8 pack8(const f32x16& v, int s) {
   for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
   return o;
 }
-// fragment [x0 x1 x2 x3 0 0 0 0] on lanes hh == 0, zeros on hh == 1 (head dim 4 padded to the 16-deep K of the MFMA)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+DEVI bf16x8 frag_of(unsigned a, unsigned b, unsigned c2, unsigned d) { return __builtin_bit_cast(bf16x8, (u32x4){a, b, c2, d}); }
+// fragment [x0 x1 x2 x3 0 0 0 0] (head dim 4 padded to the 16-deep K of the MFMA; the caller keeps it on lanes hh == 0)
 DEVI bf16x8 head_frag(const bf16* row, bool valid) {
   bf16x8 f = (bf16x8)(0);
   if (valid) {
@@ -235,35 +260,73 @@ DEVI bf16x8 head_frag(const bf16* row, bool valid) {
   }
   return f;
 }
-// LDS image of a staged [rows][E] bf16 tensor: per head MK + 1 rows of 16 bytes, [x0 x1 x2 x3 e4 0 0 0] (e4 = 1 for V in the
-// forward kernel, else 0); row MK is all zeros.  Consecutive threads take consecutive heads of one row: whole global rows,
-// and the 16-byte LDS writes of the 8 heads land 2064 B apart = on disjoint bank quads (conflict-free).
-struct StageRegs { uint2 v[MKR]; };
-DEVI void stage_load(StageRegs& rg, const bf16* src, long row0, int nrows_valid, int H, int tid, int nthr) {
+// fragment [hi(c x0..x3) | lo(c x0..x3)]
+DEVI bf16x8 scaled_frag(const bf16* row, bool valid, float c) {
+  bf16x8 f = (bf16x8)(0);
+  if (valid) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(row);
 #pragma unroll
-  for (int i = 0; i < MKR; ++i) {
-    const int idx = tid + i * nthr;
-    const int rr = idx / H, hd = idx - rr * H;
-    uint2 t = make_uint2(0, 0);
-    if (rr < nrows_valid) t = *reinterpret_cast<const uint2*>(src + (row0 + rr) * (long)(H * 4) + hd * 4);
-    rg.v[i] = t;
+    for (int d = 0; d < 4; ++d) {
+      const float x = (float)t[d] * c;
+      f[d] = (bf16)x;
+      f[4 + d] = (bf16)(x - (float)f[d]);
+    }
+  }
+  return f;
+}
+// slots j0 .. j0+2 = a three-term bf16 expansion of x (exact to fp32), the other slots zero
+DEVI bf16x8 shift_frag(float x, int j0) {
+  bf16x8 f = (bf16x8)(0);
+  const bf16 a = (bf16)x;
+  const float r1 = x - (float)a;
+  const bf16 b2 = (bf16)r1;
+  f[j0] = a; f[j0 + 1] = b2; f[j0 + 2] = (bf16)(r1 - (float)b2);
+  return f;
+}
+DEVI bf16x8 ones_frag(int j0, int n) {                        // slots j0 .. j0+n-1 = 1
+  bf16x8 f = (bf16x8)(0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j >= j0 && j < j0 + n) f[j] = (bf16)1.f;
+  return f;
+}
+DEVI bool finite_f(float x) { return fabsf(x) <= 3.0e38f; }
+DEVI void const_block(unsigned char* cb, int tid) {           // (first ATT_CONST / 8 threads)
+  if (tid < ATT_CONST / 8) {
+    const int w = tid & 7;
+    *reinterpret_cast<u32x2*>(cb + tid * 8) = (u32x2){w == 0 ? 0x3F80u : (w == 2 ? 0x3F803F80u : 0u), w == 2 ? 0x3F80u : 0u};
   }
 }
-DEVI void stage_write(const StageRegs& rg, bf16* rowL, unsigned e4, int H, int tid, int nthr) {
+// cooperative staging of one head of `src` [rows][E]: rows [row0, row0 + n) -> raw image, two rows per thread (512 threads).
+struct HeadRegs { uint2 v[ATT_HS / 512]; };
+DEVI void head_load(HeadRegs& rg, const bf16* src, long row0, int n, int E, int h, int tid) {
 #pragma unroll
-  for (int i = 0; i < MKR; ++i) {
-    const int idx = tid + i * nthr;
-    const int rr = idx / H, hd = idx - rr * H;
-    *reinterpret_cast<uint4*>(rowL + ((long)hd * (MK + 1) + rr) * 8) = make_uint4(rg.v[i].x, rg.v[i].y, e4, 0);
+  for (int i = 0; i < ATT_HS / 512; ++i) {
+    const int rr = tid + i * 512;
+    rg.v[i] = rr < n ? *reinterpret_cast<const uint2*>(src + (row0 + rr) * (long)E + h * 4) : make_uint2(0, 0);
   }
 }
-// A-operand fragment of X^T (rows = head-dim index, 8 K-slots of slice s) straight from the row image X[k][8] with the
-// hardware transposing read (cdna_hip_programming.md T10): within a 16-lane group lane 4q+p addresses row q, columns 4p..4p+3
-// and lane i receives column i of the four rows.  Lane (r, hh) so gets X[16s + j' + 8*(second read) + 4hh][r] -- the K-slot
-// order of the accumulator registers.  Columns 8..15 of a "row" are the next row's bytes: they only feed MFMA output rows
-// 8..31, which nobody reads.  The per-lane address is tr_base(); +64 elements = 8 rows for the second read.
-DEVI int tr_base(int lane) { return ((((lane & 15) >> 2) + 4 * (lane >> 5)) * 8) + 4 * (lane & 3); }
-DEVI bf16x8 tr_frag(const bf16* p) {
+DEVI void head_write(const HeadRegs& rg, unsigned char* img, int n, int tid) {
+#pragma unroll
+  for (int i = 0; i < ATT_HS / 512; ++i) {
+    const int rr = tid + i * 512;
+    if (rr < ((n + 31) & ~31)) *reinterpret_cast<uint2*>(img + rr * 8) = rg.v[i];      // (whole tiles: rows past n are zeros)
+  }
+}
+// A-operand fragment of X^T (rows = head-dim index, 8 K-slots of slice s) straight from the row image with the hardware
+// transposing read (cdna_hip_programming.md T10): within a 16-lane group lane 4q+p addresses row q, columns 4p..4p+3 and lane i
+// receives column i of the four rows.  Lane (r, hh) so gets X[16s + j' + 8*(second read) + 4hh][r] -- the K-slot order of the
+// accumulator registers.  Lanes p == 0 address the row (8 bytes = columns 0..3), lanes p >= 1 the constant block (column 4 = 1 for V
+// in the forward kernel, everything else 0): tr_ptr().  +64 B = 8 rows for the second read, +128 B the second 16-row slice, +256 B
+// the next tile; the constant block repeats every 64 B over 1 KB, so the same immediate offsets serve both kinds of lane for four
+// tiles, after which a per-lane step (1 KB for row lanes, 0 for constant lanes) moves the pointers: the sweep's address arithmetic is
+// one v_add per pointer per FOUR tiles, and the operand halves that are constants (the 1 that meets the shift, zero padding) cost
+// LDS reads instead of vector instructions -- the vector pipe is the bound (SQ_ACTIVE_INST_VALU 68 % of the SIMD cycles).
+DEVI int tr_row(int lane) { return ((lane & 15) >> 2) + 4 * (lane >> 5); }
+DEVI const unsigned char* tr_ptr(const unsigned char* img, const unsigned char* cb, int lane, bool ones) {
+  const int p = lane & 3;
+  return p == 0 ? img + tr_row(lane) * 8 : cb + ((p == 1 && ones) ? CB_ONE : CB_ZERO);
+}
+DEVI bf16x8 tr_frag(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   typedef __attribute__((address_space(3))) s16x4* lds_p;
@@ -271,239 +334,381 @@ DEVI bf16x8 tr_frag(const bf16* p) {
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 64));
   return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-DEVI void zero_row(bf16* rowL, int H, int tid, int nthr) {
-  for (int e = tid; e < H * 8; e += nthr) rowL[((long)(e >> 3) * (MK + 1) + MK) * 8 + (e & 7)] = (bf16)0.f;
+DEVI u32x2 row8(const unsigned char* p) { return *reinterpret_cast<const u32x2*>(p); }
+DEVI bf16x8 frag2(const unsigned char* lo, const unsigned char* hi) {   // two 8-byte reads = one fragment
+  const u32x2 a = row8(lo), b = row8(hi);
+  return frag_of(a.x, a.y, b.x, b.y);
 }
 
-__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(bf16* out, float* lse, const bf16* q, const bf16* k, const bf16* v, int Sq,
-                                                           int Skv, int H, float c) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
-  bf16* rowK = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
-  bf16* rowV = rowK + (long)H * (MK + 1) * 8;                 // [H][MK+1][8], element 4 of every row = 1
-  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y, q0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
-  zero_row(rowK, H, tid, nthr);
-  zero_row(rowV, H, tid, nthr);
-  const bool qok = q0 + r < Sq;
-  const bf16x8 fq = head_frag(q + ((long)b * Sq + q0 + (qok ? r : 0)) * E + h * 4, hh == 0 && qok);
-  const bf16* aK = rowK + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
-  const int aKstep = hh == 0 ? 32 * 8 : 0;
-  const bf16* aV = rowV + (long)h * (MK + 1) * 8 + tr_base(lane);
-  f32x16 o = (f32x16)(0.f);
-  float m = -INFINITY;
-  StageRegs rk, rv;
-  stage_load(rk, k, (long)b * Skv, min(MK, Skv), H, tid, nthr);
-  stage_load(rv, v, (long)b * Skv, min(MK, Skv), H, tid, nthr);
-  for (int j0 = 0; j0 < Skv; j0 += MK) {
-    __syncthreads();                                         // readers of the previous stage are done
-    stage_write(rk, rowK, 0u, H, tid, nthr);
-    stage_write(rv, rowV, 0x3F80u, H, tid, nthr);            // bf16 1.0 in column 4: O^T row 4 = sum_k P = softmax denominator
-    __syncthreads();
-    if (j0 + MK < Skv) {
-      stage_load(rk, k, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
-      stage_load(rv, v, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
-    }
-    const int nt = min(MK / 32, (Skv - j0 + 31) >> 5);
-    for (int t = 0; t < nt; ++t) {
-      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(aK + t * aKstep);
-      const bf16x8 fv0 = tr_frag(aV + t * 256);
-      const bf16x8 fv1 = tr_frag(aV + t * 256 + 128);
-      f32x16 s = mfma_bf16(fk, fq, (f32x16)(0.f));           // rows = keys, columns = queries
-      const int kb = j0 + t * 32;
-      if (kb + 32 > Skv) {
+// One sweep of a wave's 32 queries of one head over the staged keys [0, n).  fq: lanes hh == 0 [hi(c q) | lo(c q)], lanes hh == 1 zeros.
+// FAST: fixed shift (see the header); else the online maximum.  o / m carry over between key chunks (first = chunk 0 of the head).
+// Returns O^T (rows 0-3 on lanes hh == 0, the denominator = row 4 on lanes hh == 1, register 0) and the shift m in log2 units.
+template <bool FAST>
+DEVI void attn_fwd_sweep(f32x16& o, float& m, bf16x8& fqs, const bool first, const unsigned char* imgK, const unsigned char* imgV,
+                         const unsigned char* cb, const bf16x8 fq, const int n, const int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+  // K fragment = [k | k] on lanes hh == 0, [1 0 0 0 | 0] on lanes hh == 1 (slot 8 meets the shift): two 8-byte reads either way
+  const unsigned char* aK0 = hh == 0 ? imgK + r * 8 : cb + CB_ONE;
+  const unsigned char* aK1 = hh == 0 ? imgK + r * 8 : cb + CB_ZERO;
+  const unsigned char* aV = tr_ptr(imgV, cb, lane, true);
+  const int kstep = hh == 0 ? 256 : 0, vstep = (lane & 3) == 0 ? 256 : 0;
+  if (first) {
+    o = (f32x16)(0.f);
+    m = FAST ? 0.f : -INFINITY;
+    fqs = fq;
+    if (FAST) {                                              // the shift: this query's maximum over the first 32 keys, as a bf16 number
+      f32x16 s = mfma_bf16(frag2(aK0, aK1), fq, (f32x16)(0.f));
+      if (n < 32) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-          if (kb + acc_row(reg, lane) >= Skv) s[reg] = -INFINITY;
+          if (acc_row(reg, lane) >= n) s[reg] = -INFINITY;
       }
       float tm = s[0];
 #pragma unroll
       for (int reg = 1; reg < 16; ++reg) tm = fmaxf(tm, s[reg]);
       tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                // the other half-wave holds the other 16 keys of these queries
-      const float mn = fmaxf(m, tm);
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-      m = mn;
-      const float nm = -mn * c;
-      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;     // rows 0-3 (hh = 0) and the denominator row 4 (hh = 1)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(fmaf(s[reg], c, nm));
-      o = mfma_bf16(fv0, pack8(s, 0), o);
-      o = mfma_bf16(fv1, pack8(s, 1), o);
+      const bf16 sh = (bf16)(-tm);
+      m = -(float)sh;
+      if (hh == 1) fqs[0] = sh;
     }
   }
-  const float l = __shfl_xor(o[0], 32, 64);                  // row 4 of O^T (lane + 32, register 0) = sum of the probabilities
-  if (hh == 0 && qok) {
-    const float il = 1.f / l;
-    bf16x4 ov;
-    ov[0] = (bf16)(o[0] * il); ov[1] = (bf16)(o[1] * il); ov[2] = (bf16)(o[2] * il); ov[3] = (bf16)(o[3] * il);
-    *reinterpret_cast<bf16x4*>(out + ((long)b * Sq + q0 + r) * E + h * 4) = ov;
-    lse[((long)b * H + h) * Sq + q0 + r] = (m * c + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  auto tile = [&](const int off, const int kb, const bool partial) {
+    const bf16x8 fk = frag2(aK0 + off, aK1 + off);
+    const bf16x8 fv0 = tr_frag(aV + off);
+    const bf16x8 fv1 = tr_frag(aV + off + 128);
+    f32x16 s = mfma_bf16(fk, fqs, (f32x16)(0.f));            // rows = keys, columns = queries; log2 units, minus the shift if FAST
+    if (partial) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (kb + acc_row(reg, lane) >= n) s[reg] = -INFINITY;
+    }
+    if (FAST) {
+#if HDMOE_ATTN_DBG != 1 && HDMOE_ATTN_DBG != 3
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(s[reg]);
+#endif
+    } else {
+      float tm = s[0];
+#pragma unroll
+      for (int reg = 1; reg < 16; ++reg) tm = fmaxf(tm, s[reg]);
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float mn = fmaxf(m, tm);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;       // rows 0-3 (hh = 0) and the denominator row 4 (hh = 1)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(s[reg] - mn);
+    }
+#if HDMOE_ATTN_DBG == 2 || HDMOE_ATTN_DBG == 3
+    o[0] += s[0] + s[5] + s[10] + s[15]; o[1] += s[1] + s[4] + s[11] + s[14]; o[2] += s[2] + s[7] + s[8] + s[13]; o[3] += s[3] + s[6] + s[9] + s[12];
+#else
+    o = mfma_bf16(fv0, pack8(s, 0), o);
+    o = mfma_bf16(fv1, pack8(s, 1), o);
+#endif
+  };
+  int kb = 0;
+  for (; kb + 128 <= n; kb += 128) {                          // four full tiles per pointer step
+    tile(0, kb, false); tile(256, kb + 32, false); tile(512, kb + 64, false); tile(768, kb + 96, false);
+    aK0 += 4 * kstep; aK1 += 4 * kstep; aV += 4 * vstep;
+  }
+  for (; kb < n; kb += 32) {
+    tile(0, kb, kb + 32 > n);
+    aK0 += kstep; aK1 += kstep; aV += vstep;
   }
 }
 
-// dq (+ delta): wave = (head, 32 queries); keys stream through LDS.
+// grid (ceil(Sq / 256), B), 512 threads: wave w = queries [blockIdx.x * 256 + 32 w, +32) of sample blockIdx.y, all heads in turn.
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(bf16* out, float* lse, const bf16* q, const bf16* k, const bf16* v, int Sq,
+                                                           int Skv, int H, float c, int force_slow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  unsigned char* cb = smem_attn + 4 * ATT_IMG;                // [2 buffers][K | V] raw images, then the constant block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, q0 = blockIdx.x * 256 + wave * 32, E = H * 4;
+  const bool qok = q0 + r < Sq;
+  const long qrow = ((long)b * Sq + q0 + (qok ? r : 0)) * E;
+  const int nch = (Skv + ATT_HS - 1) / ATT_HS, nst = H * nch;
+  const bool slow = force_slow != 0 || nch > 1;               // (the repeat-on-overflow needs the head's keys in ONE image)
+  const_block(cb, tid);
+  HeadRegs rk, rv;
+  head_load(rk, k, (long)b * Skv, min(ATT_HS, Skv), E, 0, tid);
+  head_load(rv, v, (long)b * Skv, min(ATT_HS, Skv), E, 0, tid);
+  head_write(rk, smem_attn, min(ATT_HS, Skv), tid);
+  head_write(rv, smem_attn + ATT_IMG, min(ATT_HS, Skv), tid);
+  __syncthreads();
+  f32x16 o;
+  float m;
+  bf16x8 fq, fqs;
+  for (int st = 0; st < nst; ++st) {
+    const int h = st / nch, ch = st - h * nch, n = min(ATT_HS, Skv - ch * ATT_HS);
+    const unsigned char* imgK = smem_attn + (st & 1) * 2 * ATT_IMG;
+    const unsigned char* imgV = imgK + ATT_IMG;
+    int nn = 0;
+    if (st + 1 < nst) {                                       // the next head / chunk: global -> registers beside this sweep
+      const int h2 = (st + 1) / nch, ch2 = st + 1 - h2 * nch;
+      nn = min(ATT_HS, Skv - ch2 * ATT_HS);
+      head_load(rk, k, (long)b * Skv + ch2 * ATT_HS, nn, E, h2, tid);
+      head_load(rv, v, (long)b * Skv + ch2 * ATT_HS, nn, E, h2, tid);
+    }
+    if (ch == 0) fq = scaled_frag(q + qrow + h * 4, hh == 0 && qok, c);
+    if (slow) attn_fwd_sweep<false>(o, m, fqs, ch == 0, imgK, imgV, cb, fq, n, lane);
+    else {
+      attn_fwd_sweep<true>(o, m, fqs, true, imgK, imgV, cb, fq, n, lane);
+      const float l0 = __shfl_xor(o[0], 32, 64);
+      const bool bad = HDMOE_ATTN_DBG == 0 && hh == 0 && !(finite_f(o[0]) && finite_f(o[1]) && finite_f(o[2]) && finite_f(o[3]) && finite_f(l0) && l0 > 0.f);
+      if (__builtin_amdgcn_ballot_w64(bad) != 0)              // (never on the model's activations; tests force it)
+        attn_fwd_sweep<false>(o, m, fqs, true, imgK, imgV, cb, fq, n, lane);
+    }
+    if (ch == nch - 1) {
+      const float l = __shfl_xor(o[0], 32, 64);               // row 4 of O^T (lane + 32, register 0) = sum of the probabilities
+      if (hh == 0 && qok) {
+        const float il = 1.f / l;
+        bf16x4 ov;
+        ov[0] = (bf16)(o[0] * il); ov[1] = (bf16)(o[1] * il); ov[2] = (bf16)(o[2] * il); ov[3] = (bf16)(o[3] * il);
+        *reinterpret_cast<bf16x4*>(out + qrow + h * 4) = ov;
+        lse[((long)b * H + h) * Sq + q0 + r] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+      }
+    }
+    if (st + 1 < nst) {
+      unsigned char* nxt = smem_attn + ((st + 1) & 1) * 2 * ATT_IMG;   // last read in stage st - 1: every wave has passed that stage's barrier
+      head_write(rk, nxt, nn, tid);
+      head_write(rv, nxt + ATT_IMG, nn, tid);
+      __syncthreads();
+    }
+  }
+}
+
+// dq (+ delta): wave = 32 queries, heads in turn; the head's keys / values staged as in the forward kernel.
 __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_kernel(bf16* dq, float* delta, const bf16* dout, const bf16* out, const bf16* q,
                                                               const bf16* k, const bf16* v, const float* lse, int Sq, int Skv, int H,
                                                               float scale, float c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
-  bf16* rowK = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
-  bf16* rowV = rowK + (long)H * (MK + 1) * 8;                 // [H][MK+1][8]
-  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y, q0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
-  zero_row(rowK, H, tid, nthr);
-  zero_row(rowV, H, tid, nthr);
+  unsigned char* cb = smem_attn + 4 * ATT_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, q0 = blockIdx.x * 256 + wave * 32, E = H * 4;
   const bool qok = q0 + r < Sq;
-  const long qoff = ((long)b * Sq + q0 + (qok ? r : 0)) * E + h * 4;
-  const bf16x8 fq = head_frag(q + qoff, hh == 0 && qok);
-  const bf16x8 fdo = head_frag(dout + qoff, hh == 0 && qok);
-  float dl = 0.f, ls = 0.f;
-  if (qok) {
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(dout + qoff), o4 = *reinterpret_cast<const bf16x4*>(out + qoff);
-    dl = (float)a[0] * (float)o4[0] + (float)a[1] * (float)o4[1] + (float)a[2] * (float)o4[2] + (float)a[3] * (float)o4[3];
-    ls = lse[((long)b * H + h) * Sq + q0 + r] * 1.4426950408889634f;
-    if (hh == 0) delta[((long)b * H + h) * Sq + q0 + r] = dl;
-  }
-  const long lstep = hh == 0 ? 32 * 8 : 0;
-  const bf16* aK = rowK + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
-  const bf16* aVr = rowV + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
-  const bf16* aKt = rowK + (long)h * (MK + 1) * 8 + tr_base(lane);
-  f32x16 acc = (f32x16)(0.f);
-  StageRegs rk, rv;
-  stage_load(rk, k, (long)b * Skv, min(MK, Skv), H, tid, nthr);
-  stage_load(rv, v, (long)b * Skv, min(MK, Skv), H, tid, nthr);
-  for (int j0 = 0; j0 < Skv; j0 += MK) {
-    __syncthreads();
-    stage_write(rk, rowK, 0u, H, tid, nthr);
-    stage_write(rv, rowV, 0u, H, tid, nthr);
-    __syncthreads();
-    if (j0 + MK < Skv) {
-      stage_load(rk, k, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
-      stage_load(rv, v, (long)b * Skv + j0 + MK, min(MK, Skv - j0 - MK), H, tid, nthr);
+  const long qrow = ((long)b * Sq + q0 + (qok ? r : 0)) * E;
+  const int nch = (Skv + ATT_HS - 1) / ATT_HS, nst = H * nch;
+  const_block(cb, tid);
+  HeadRegs rk, rv;
+  head_load(rk, k, (long)b * Skv, min(ATT_HS, Skv), E, 0, tid);
+  head_load(rv, v, (long)b * Skv, min(ATT_HS, Skv), E, 0, tid);
+  head_write(rk, smem_attn, min(ATT_HS, Skv), tid);
+  head_write(rv, smem_attn + ATT_IMG, min(ATT_HS, Skv), tid);
+  __syncthreads();
+  const int kstep = (lane & 3) == 0 ? 256 : 0, rstep = hh == 0 ? 256 : 0;
+  f32x16 acc;
+  bf16x8 fq, fdo;
+  for (int st = 0; st < nst; ++st) {
+    const int h = st / nch, ch = st - h * nch, n = min(ATT_HS, Skv - ch * ATT_HS);
+    const unsigned char* imgK = smem_attn + (st & 1) * 2 * ATT_IMG;
+    const unsigned char* imgV = imgK + ATT_IMG;
+    int nn = 0;
+    if (st + 1 < nst) {
+      const int h2 = (st + 1) / nch, ch2 = st + 1 - h2 * nch;
+      nn = min(ATT_HS, Skv - ch2 * ATT_HS);
+      head_load(rk, k, (long)b * Skv + ch2 * ATT_HS, nn, E, h2, tid);
+      head_load(rv, v, (long)b * Skv + ch2 * ATT_HS, nn, E, h2, tid);
     }
-    const int nt = min(MK / 32, (Skv - j0 + 31) >> 5);
-    for (int t = 0; t < nt; ++t) {
-      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(aK + t * lstep);
-      const bf16x8 fv = *reinterpret_cast<const bf16x8*>(aVr + t * lstep);
-      const bf16x8 fk0 = tr_frag(aKt + t * 256);
-      const bf16x8 fk1 = tr_frag(aKt + t * 256 + 128);
-      f32x16 s = mfma_bf16(fk, fq, (f32x16)(0.f));           // S^T[k][q]
-      const f32x16 dp = mfma_bf16(fv, fdo, (f32x16)(0.f));   // dP^T[k][q] = V[k] . dO[q]
+    if (ch == 0) {
+      const long qoff = qrow + h * 4;
+      float dl = 0.f, ls = 0.f;
+      if (qok) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(dout + qoff), o4 = *reinterpret_cast<const bf16x4*>(out + qoff);
+        dl = (float)a[0] * (float)o4[0] + (float)a[1] * (float)o4[1] + (float)a[2] * (float)o4[2] + (float)a[3] * (float)o4[3];
+        ls = lse[((long)b * H + h) * Sq + q0 + r] * 1.4426950408889634f;
+        if (hh == 0) delta[((long)b * H + h) * Sq + q0 + r] = dl;
+      }
+      // S'^T = c q.k - lse (log2 units) and dP'^T = V.dO - delta come out of the matrix pipe: slots 8-10 carry the two shifts
+      fq = hh == 0 ? scaled_frag(q + qoff, qok, c) : shift_frag(-ls, 0);
+      fdo = hh == 0 ? head_frag(dout + qoff, qok) : shift_frag(-dl, 0);
+      acc = (f32x16)(0.f);
+    }
+    // K fragment [k | k] / V fragment [v | 0] on lanes hh == 0, [1 1 1 0 | 0] on lanes hh == 1 (slots 8-10 meet the shifts)
+    const unsigned char* aK0 = hh == 0 ? imgK + r * 8 : cb + CB_ONE3;
+    const unsigned char* aK1 = hh == 0 ? imgK + r * 8 : cb + CB_ZERO;
+    const unsigned char* aV0 = hh == 0 ? imgV + r * 8 : cb + CB_ONE3;
+    const unsigned char* aZ = cb + CB_ZERO;
+    const unsigned char* aKt = tr_ptr(imgK, cb, lane, false);
+    auto tile = [&](const int off) {
+      const bf16x8 fk = frag2(aK0 + off, aK1 + off);
+      const bf16x8 fv = frag2(aV0 + off, aZ + off);
+      const bf16x8 fk0 = tr_frag(aKt + off);
+      const bf16x8 fk1 = tr_frag(aKt + off + 128);
+      f32x16 s = mfma_bf16(fk, fq, (f32x16)(0.f));           // S'^T[k][q]
+      const f32x16 dp = mfma_bf16(fv, fdo, (f32x16)(0.f));   // dP'^T[k][q] = V[k] . dO[q] - delta[q]
       // keys past Skv are zero rows: their ds is finite and meets a zero K^T column, so no masking is needed
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(fmaf(s[reg], c, -ls)) * (dp[reg] - dl);
+      for (int reg = 0; reg < 16; ++reg) s[reg] = __builtin_amdgcn_exp2f(s[reg]) * dp[reg];
       acc = mfma_bf16(fk0, pack8(s, 0), acc);                // dQ^T[d][q] += K^T[d][k] dS^T[k][q]
       acc = mfma_bf16(fk1, pack8(s, 1), acc);
+    };
+    int kb = 0;
+    for (; kb + 128 <= n; kb += 128) {
+      tile(0); tile(256); tile(512); tile(768);
+      aK0 += 4 * rstep; aK1 += 4 * rstep; aV0 += 4 * rstep; aKt += 4 * kstep;
     }
-  }
-  if (hh == 0 && qok) {
-    bf16x4 ov;
-    ov[0] = (bf16)(acc[0] * scale); ov[1] = (bf16)(acc[1] * scale); ov[2] = (bf16)(acc[2] * scale); ov[3] = (bf16)(acc[3] * scale);
-    *reinterpret_cast<bf16x4*>(dq + qoff) = ov;
+    for (; kb < n; kb += 32) {
+      tile(0);
+      aK0 += rstep; aK1 += rstep; aV0 += rstep; aKt += kstep;
+    }
+    if (ch == nch - 1 && hh == 0 && qok) {
+      bf16x4 ov;
+      ov[0] = (bf16)(acc[0] * scale); ov[1] = (bf16)(acc[1] * scale); ov[2] = (bf16)(acc[2] * scale); ov[3] = (bf16)(acc[3] * scale);
+      *reinterpret_cast<bf16x4*>(dq + qrow + h * 4) = ov;
+    }
+    if (st + 1 < nst) {
+      unsigned char* nxt = smem_attn + ((st + 1) & 1) * 2 * ATT_IMG;
+      head_write(rk, nxt, nn, tid);
+      head_write(rv, nxt + ATT_IMG, nn, tid);
+      __syncthreads();
+    }
   }
 }
 
-// dk, dv: wave = (head, 32 keys); queries (+ dO, lse, delta) stream through LDS.
+// dk, dv: wave = 32 keys, heads in turn; the head's queries and dO rows staged raw, plus a 16-byte row of shifts per query,
+// [-lse hi, lo, 0, 0 | -delta hi, mid, lo, 0]: the A fragment of the half-wave hh == 1 in BOTH first products (the K operand holds ones in
+// slots 8-9, the V operand in slots 12-14).
+constexpr int ATT_KV_BUF = 2 * ATT_IMG + ATT_HS * 16;        // Q | dO | shifts
 __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(bf16* dk, bf16* dv, const bf16* dout, const bf16* q, const bf16* k,
                                                                const bf16* v, const float* lse, const float* delta, int Sq, int Skv,
-                                                               int H, float scale, float c) {
+                                                               int H, float scale, float c, int nkb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
-  bf16* rowQ = reinterpret_cast<bf16*>(smem_attn);           // [H][MK+1][8]
-  bf16* rowD = rowQ + (long)H * (MK + 1) * 8;                 // [H][MK+1][8]
-  float* sl = reinterpret_cast<float*>(rowD + (long)H * (MK + 1) * 8);   // [H][MK] lse * log2(e)  (+inf past Sq)
-  float* sd = sl + (long)H * MK;                              // [H][MK] delta
-  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y, k0 = blockIdx.x * 32, E = H * 4, nthr = H * 64;
-  zero_row(rowQ, H, tid, nthr);
-  zero_row(rowD, H, tid, nthr);
+  unsigned char* cb = smem_attn + 2 * ATT_KV_BUF;
+  float* red = reinterpret_cast<float*>(cb + ATT_CONST);      // [8 waves][32 keys][8] partial dK | dV of the query splits
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  // nkb (1, 2, 4 or 8) key blocks per workgroup; with fewer than 8 the waves of a key block split the queries 8 / nkb ways (the text
+  // cross-attention has 77 keys: 3 blocks) and the partial sums meet in LDS at the end of a head
+  const int kbw = wave & (nkb - 1), split = wave / nkb, nsplit = 8 / nkb;
+  const int b = blockIdx.y, k0 = (blockIdx.x * nkb + kbw) * 32, E = H * 4;
   const bool kok = k0 + r < Skv;
-  const long koff = ((long)b * Skv + k0 + (kok ? r : 0)) * E + h * 4;
-  const bf16x8 fkB = head_frag(k + koff, hh == 0 && kok);
-  const bf16x8 fvB = head_frag(v + koff, hh == 0 && kok);
-  const long lstep = hh == 0 ? 32 * 8 : 0;
-  const bf16* aQ = rowQ + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
-  const bf16* aD = rowD + ((long)h * (MK + 1) + (hh == 0 ? r : MK)) * 8;
-  const bf16* aQt = rowQ + (long)h * (MK + 1) * 8 + tr_base(lane);
-  const bf16* aDt = rowD + (long)h * (MK + 1) * 8 + tr_base(lane);
-  const float* pl = sl + (long)h * MK + 4 * hh;
-  const float* pd = sd + (long)h * MK + 4 * hh;
-  f32x16 ak = (f32x16)(0.f), av = (f32x16)(0.f);
-  StageRegs rq, rd;
-  float rl[MKR], rdl[MKR];
-  auto load_ld = [&](int i0) {
+  const long krow = ((long)b * Skv + k0 + (kok ? r : 0)) * E;
+  const int nch = (Sq + ATT_HS - 1) / ATT_HS, nst = H * nch;
+  const_block(cb, tid);
+  HeadRegs rq, rd;
+  float rl[ATT_HS / 512], rdl[ATT_HS / 512];
+  auto stage_load = [&](int st) {
+    const int h2 = st / nch, ch2 = st - h2 * nch, i0 = ch2 * ATT_HS, nv = min(ATT_HS, Sq - i0);
+    head_load(rq, q, (long)b * Sq + i0, nv, E, h2, tid);
+    head_load(rd, dout, (long)b * Sq + i0, nv, E, h2, tid);
 #pragma unroll
-    for (int i = 0; i < MKR; ++i) {
-      const int idx = tid + i * nthr;
-      const int rr = idx / H, hd = idx - rr * H;
-      const bool ok = i0 + rr < Sq;
-      rl[i] = ok ? lse[((long)b * H + hd) * Sq + i0 + rr] * 1.4426950408889634f : INFINITY;
-      rdl[i] = ok ? delta[((long)b * H + hd) * Sq + i0 + rr] : 0.f;
+    for (int i = 0; i < ATT_HS / 512; ++i) {
+      const int rr = tid + i * 512;
+      rl[i] = rr < nv ? lse[((long)b * H + h2) * Sq + i0 + rr] * 1.4426950408889634f : 1.0e4f;   // queries past Sq: p = exp2(-1e4) = 0
+      rdl[i] = rr < nv ? delta[((long)b * H + h2) * Sq + i0 + rr] : 0.f;
+    }
+    return nv;
+  };
+  auto stage_write = [&](int st, int nv) {
+    unsigned char* buf = smem_attn + (st & 1) * ATT_KV_BUF;
+    head_write(rq, buf, nv, tid);
+    head_write(rd, buf + ATT_IMG, nv, tid);
+#pragma unroll
+    for (int i = 0; i < ATT_HS / 512; ++i) {
+      const int rr = tid + i * 512;
+      if (rr < ((nv + 31) & ~31)) {
+        const bf16x8 a = shift_frag(-rl[i], 0);
+        bf16x8 w = shift_frag(-rdl[i], 4);
+        w[0] = a[0]; w[1] = a[1];
+        *reinterpret_cast<bf16x8*>(buf + 2 * ATT_IMG + rr * 16) = w;
+      }
     }
   };
-  stage_load(rq, q, (long)b * Sq, min(MK, Sq), H, tid, nthr);
-  stage_load(rd, dout, (long)b * Sq, min(MK, Sq), H, tid, nthr);
-  load_ld(0);
-  for (int i0 = 0; i0 < Sq; i0 += MK) {
-    __syncthreads();
-    stage_write(rq, rowQ, 0u, H, tid, nthr);
-    stage_write(rd, rowD, 0u, H, tid, nthr);
-#pragma unroll
-    for (int i = 0; i < MKR; ++i) {
-      const int idx = tid + i * nthr;
-      const int rr = idx / H, hd = idx - rr * H;
-      sl[(long)hd * MK + rr] = rl[i];
-      sd[(long)hd * MK + rr] = rdl[i];
+  int nv0 = stage_load(0);
+  stage_write(0, nv0);
+  __syncthreads();
+  const bf16x8 onesK = ones_frag(0, 2), onesV = ones_frag(4, 3);
+  const int tstep = (lane & 3) == 0 ? 256 : 0, astep = hh == 0 ? 256 : 512;
+  f32x16 ak, av;
+  bf16x8 fkB, fvB;
+  for (int st = 0; st < nst; ++st) {
+    const int h = st / nch, ch = st - h * nch, n = min(ATT_HS, Sq - ch * ATT_HS);
+    const unsigned char* imgQ = smem_attn + (st & 1) * ATT_KV_BUF;
+    const unsigned char* imgD = imgQ + ATT_IMG;
+    const unsigned char* imgS = imgD + ATT_IMG;
+    int nn = 0;
+    if (st + 1 < nst) nn = stage_load(st + 1);
+    if (ch == 0) {
+      fkB = hh == 0 ? scaled_frag(k + krow + h * 4, kok, c) : onesK;
+      fvB = hh == 0 ? head_frag(v + krow + h * 4, kok) : onesV;
+      ak = (f32x16)(0.f); av = (f32x16)(0.f);
     }
-    __syncthreads();
-    if (i0 + MK < Sq) {
-      stage_load(rq, q, (long)b * Sq + i0 + MK, min(MK, Sq - i0 - MK), H, tid, nthr);
-      stage_load(rd, dout, (long)b * Sq + i0 + MK, min(MK, Sq - i0 - MK), H, tid, nthr);
-      load_ld(i0 + MK);
-    }
-    const int nt = min(MK / 32, (Sq - i0 + 31) >> 5);
-    for (int t = 0; t < nt; ++t) {
-      const bf16x8 fqr = *reinterpret_cast<const bf16x8*>(aQ + t * lstep);
-      const bf16x8 fdr = *reinterpret_cast<const bf16x8*>(aD + t * lstep);
-      const bf16x8 fd0 = tr_frag(aDt + t * 256), fd1 = tr_frag(aDt + t * 256 + 128);
-      const bf16x8 fq0 = tr_frag(aQt + t * 256), fq1 = tr_frag(aQt + t * 256 + 128);
-      f32x16 s = mfma_bf16(fqr, fkB, (f32x16)(0.f));          // S[q][k]: rows = queries, columns = keys
-      f32x16 dp = mfma_bf16(fdr, fvB, (f32x16)(0.f));         // dP[q][k] = dO[q] . V[k]
+    // A fragments: lanes hh == 0 [q | q] and [dO | 0], lanes hh == 1 the query's shift row (both products)
+    const unsigned char* aQ0 = hh == 0 ? imgQ + r * 8 : imgS + r * 16;
+    const unsigned char* aQ1 = hh == 0 ? imgQ + r * 8 : imgS + r * 16 + 8;
+    const unsigned char* aD0 = hh == 0 ? imgD + r * 8 : imgS + r * 16;
+    const unsigned char* aD1 = hh == 0 ? cb + CB_ZERO : imgS + r * 16 + 8;
+    const unsigned char* aQt = tr_ptr(imgQ, cb, lane, false);
+    const unsigned char* aDt = tr_ptr(imgD, cb, lane, false);
+    const int d1step = hh == 0 ? 0 : 512;
+    auto tile = [&](const int off) {                          // (off counts 256-byte row tiles; the shift rows are twice as wide)
+      const int offa = hh == 0 ? off : 2 * off;
+      const bf16x8 fqr = frag2(aQ0 + offa, aQ1 + offa);
+      const bf16x8 fdr = frag2(aD0 + offa, aD1 + offa);
+      const bf16x8 fd0 = tr_frag(aDt + off), fd1 = tr_frag(aDt + off + 128);
+      const bf16x8 fq0 = tr_frag(aQt + off), fq1 = tr_frag(aQt + off + 128);
+      f32x16 s = mfma_bf16(fqr, fkB, (f32x16)(0.f));          // S'[q][k] = c q.k - lse[q]: rows = queries, columns = keys
+      f32x16 dp = mfma_bf16(fdr, fvB, (f32x16)(0.f));         // dP'[q][k] = dO[q] . V[k] - delta[q]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                           // register quad i = queries 8i + 4hh .. +3 of the tile
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(pl + t * 32 + 8 * i);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(pd + t * 32 + 8 * i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * i + j], c, -l4[j]));    // 0 for queries past Sq (lse = +inf)
-          s[4 * i + j] = p;
-          dp[4 * i + j] = p * (dp[4 * i + j] - d4[j]);
-        }
+      for (int reg = 0; reg < 16; ++reg) {
+        s[reg] = __builtin_amdgcn_exp2f(s[reg]);
+        dp[reg] *= s[reg];
       }
       av = mfma_bf16(fd0, pack8(s, 0), av);                   // dV^T[d][k] += dO^T[d][q] P[q][k]
       av = mfma_bf16(fd1, pack8(s, 1), av);
       ak = mfma_bf16(fq0, pack8(dp, 0), ak);                  // dK^T[d][k] += Q^T[d][q] dS[q][k]
       ak = mfma_bf16(fq1, pack8(dp, 1), ak);
+    };
+    const int ntq = (n + 31) >> 5, t0 = split * ntq / nsplit, t1 = (split + 1) * ntq / nsplit;
+    aQ0 += t0 * astep; aQ1 += t0 * astep; aD0 += t0 * astep; aD1 += t0 * d1step; aQt += t0 * tstep; aDt += t0 * tstep;
+    for (int t = t0; t < t1; ++t) {
+      tile(0);
+      aQ0 += astep; aQ1 += astep; aD0 += astep; aD1 += d1step; aQt += tstep; aDt += tstep;
     }
-  }
-  if (hh == 0 && kok) {
-    bf16x4 ok4, ov4;
-    ok4[0] = (bf16)(ak[0] * scale); ok4[1] = (bf16)(ak[1] * scale); ok4[2] = (bf16)(ak[2] * scale); ok4[3] = (bf16)(ak[3] * scale);
-    ov4[0] = (bf16)av[0]; ov4[1] = (bf16)av[1]; ov4[2] = (bf16)av[2]; ov4[3] = (bf16)av[3];
-    *reinterpret_cast<bf16x4*>(dk + koff) = ok4;
-    *reinterpret_cast<bf16x4*>(dv + koff) = ov4;
+    if (nsplit > 1 && ch == nch - 1) {                        // (uniform over the workgroup)
+      float* mine = red + ((long)wave * 32 + r) * 8;
+      if (split > 0 && hh == 0) {
+        *reinterpret_cast<f32x4*>(mine) = (f32x4){ak[0], ak[1], ak[2], ak[3]};
+        *reinterpret_cast<f32x4*>(mine + 4) = (f32x4){av[0], av[1], av[2], av[3]};
+      }
+      __syncthreads();
+      if (split == 0 && hh == 0) {
+        for (int sp = 1; sp < nsplit; ++sp) {
+          const float* o2 = red + ((long)(sp * nkb + kbw) * 32 + r) * 8;
+          const f32x4 pk = *reinterpret_cast<const f32x4*>(o2), pv = *reinterpret_cast<const f32x4*>(o2 + 4);
+          ak[0] += pk[0]; ak[1] += pk[1]; ak[2] += pk[2]; ak[3] += pk[3];
+          av[0] += pv[0]; av[1] += pv[1]; av[2] += pv[2]; av[3] += pv[3];
+        }
+      }
+    }
+    if (ch == nch - 1 && hh == 0 && kok && split == 0) {
+      bf16x4 ok4, ov4;
+      ok4[0] = (bf16)(ak[0] * scale); ok4[1] = (bf16)(ak[1] * scale); ok4[2] = (bf16)(ak[2] * scale); ok4[3] = (bf16)(ak[3] * scale);
+      ov4[0] = (bf16)av[0]; ov4[1] = (bf16)av[1]; ov4[2] = (bf16)av[2]; ov4[3] = (bf16)av[3];
+      *reinterpret_cast<bf16x4*>(dk + krow + h * 4) = ok4;
+      *reinterpret_cast<bf16x4*>(dv + krow + h * 4) = ov4;
+    }
+    if (st + 1 < nst) {
+      stage_write(st + 1, nn);
+      __syncthreads();
+    }
   }
 }
 
 static inline bool attn_mfma_ok(int H, const void* a, const void* b2, const void* c2, const void* d2) {
   static const bool off = getenv("HDMOE_ATTN_VALU") != nullptr;
-  return !off && H >= 1 && H <= 8 && (((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 7) == 0;
+  return !off && H >= 1 && H <= 4096 && (((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 7) == 0;
 }
 
-static void attn_mfma_attrs() {                              // (the staged images exceed the 64 KB default with MK = 256)
+static int attn_force_slow() {                                // (tests: the online-maximum sweep of the forward kernel for every block)
+  const char* e = getenv("HDMOE_ATTN_SLOW");
+  return e && atoi(e) != 0;
+}
+
+static void attn_mfma_attrs() {                              // (the dk / dv kernel's two buffers are 64 KB + the constant block)
   static bool done = false;
   if (done) return;
   done = true;
-  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_KV_BUF + ATT_CONST + 8 * 32 * 8 * 4);
 }
 
 template <typename T, int D>
@@ -511,10 +716,10 @@ int attn_fwd_launch(void* out, float* lse, const void* q, const void* k, const v
                     int H, int Sb, hipStream_t st) {
   if constexpr (sizeof(T) == 2 && D == 4) {
     if (!bias && attn_mfma_ok(H, out, q, k, v)) {
-      const size_t lds = (size_t)H * 2 * (MK + 1) * 16;
+      const size_t lds = 4 * ATT_IMG + ATT_CONST;
       attn_mfma_attrs();
-      hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds, st, (bf16*)out, lse, (const bf16*)q, (const bf16*)k,
-                         (const bf16*)v, Sq, Skv, H, 1.4426950408889634f / sqrtf((float)D));
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(cdiv(Sq, 256), B), dim3(512), lds, st, (bf16*)out, lse, (const bf16*)q, (const bf16*)k,
+                         (const bf16*)v, Sq, Skv, H, 1.4426950408889634f / sqrtf((float)D), attn_force_slow());
       return hdmoe_launch_status();
     }
   }
@@ -533,13 +738,13 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
   if constexpr (sizeof(T) == 2 && D == 4) {
     if (!bias && attn_mfma_ok(H, dq, dk, dv, dout) && attn_mfma_ok(H, out, q, k, v)) {
       const float c = scale * 1.4426950408889634f;
-      const size_t lds_q = (size_t)H * 2 * (MK + 1) * 16;
-      const size_t lds_kv = (size_t)H * (2 * (MK + 1) * 16 + 2 * MK * 4);
+      const size_t lds_q = 4 * ATT_IMG + ATT_CONST, lds_kv = 2 * ATT_KV_BUF + ATT_CONST + 8 * 32 * 8 * 4;
+      const int nb32 = (int)cdiv(Skv, 32), nkb = nb32 >= 5 ? 8 : (nb32 >= 3 ? 4 : nb32);
       attn_mfma_attrs();
-      hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(Sq, 32), B), dim3(64 * H), lds_q, st, (bf16*)dq, delta, (const bf16*)dout,
+      hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(Sq, 256), B), dim3(512), lds_q, st, (bf16*)dq, delta, (const bf16*)dout,
                          (const bf16*)out, (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, Sq, Skv, H, scale, c);
-      hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(Skv, 32), B), dim3(64 * H), lds_kv, st, (bf16*)dk, (bf16*)dv, (const bf16*)dout,
-                         (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, Sq, Skv, H, scale, c);
+      hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(Skv, 32 * nkb), B), dim3(512), lds_kv, st, (bf16*)dk, (bf16*)dv, (const bf16*)dout,
+                         (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, Sq, Skv, H, scale, c, nkb);
       return hdmoe_launch_status();
     }
   }

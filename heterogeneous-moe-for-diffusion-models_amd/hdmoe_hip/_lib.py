@@ -12,7 +12,7 @@ from typing import Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhdmoe_hip.so")
+LIB_PATH = os.environ.get("HDMOE_LIB_PATH") or os.path.join(_HERE, "libhdmoe_hip.so")   # (override: development ablation builds)
 
 F32, BF16 = 0, 1
 MAX_GROUPS = 8

@@ -617,6 +617,48 @@ def test_attention_vs_torch(dtype, rel, B, Sq, Skv, H, D, bias):
         close_scaled(bd.grad, br.grad, rel, msg="dbias")
 
 
+@pytest.mark.parametrize("B,Sq,Skv,H,sq,sk,first", [
+    (2, 1024, 1024, 8, 1.0, 1.0, None), (3, 300, 77, 8, 1.0, 1.0, None), (2, 96, 40, 3, 1.0, 1.0, None), (1, 33, 20, 8, 1.0, 1.0, None),
+    (1, 300, 1100, 2, 1.0, 1.0, None),                # more keys than one staged head image: chunked, online maximum
+    (1, 1100, 64, 2, 1.0, 1.0, None),                 # more queries than one staged head image (the dk / dv kernel's chunks)
+    (2, 256, 256, 8, 6.0, 6.0, None),                 # |scores| in the hundreds
+    (2, 128, 256, 8, 8.0, 30.0, 1e-3),                # later keys beat the first-tile shift by > 2^127: the wave repeats with the online maximum
+    (2, 128, 256, 8, 8.0, 0.05, 600.0)])              # the first tile dominates everything after it
+def test_mfma_attention_shift_paths_match_an_fp64_softmax(B, Sq, Skv, H, sq, sk, first):
+    """The bf16 D = 4 attention kernels carry the softmax shift in the padding slots of the score MFMA (csrc/attention.hip): the
+    forward with its first-tile shift, forced onto the online-maximum sweep (HDMOE_ATTN_SLOW), and on inputs where the first-tile
+    shift overflows, against an fp64 softmax of the same bf16 operands; lse and the three gradients with it."""
+    import os
+    from hdmoe_hip._lib import call
+    torch.manual_seed(Sq * 7 + Skv)
+    E, D = H * 4, 4
+    q = (sq * torch.randn(B, Sq, E)).bfloat16().to(DEV)
+    k = (sk * torch.randn(B, Skv, E)).bfloat16().to(DEV)
+    if first is not None:
+        k[:, :32] *= first
+    v = torch.randn(B, Skv, E).bfloat16().to(DEV)
+    go = torch.randn(B, Sq, E).bfloat16().to(DEV)
+    qr, kr, vr = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
+    s = (qr.view(B, Sq, H, D).transpose(1, 2) @ kr.view(B, Skv, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+    ref = (s.softmax(-1) @ vr.view(B, Skv, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, Sq, E)
+    ref.backward(go.double().cpu())
+    refs = (ref.detach(), torch.logsumexp(s, -1).detach(), qr.grad, kr.grad, vr.grad)
+    try:
+        for slow in ("0", "1"):
+            os.environ["HDMOE_ATTN_SLOW"] = slow
+            out = torch.empty_like(q); lse = torch.empty(B, H, Sq, device=DEV)
+            call("hdmoe_attn_fwd", out, lse, q, k, v, None, B, Sq, Skv, H, D, 0, 1)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            delta = torch.empty(B, H, Sq, device=DEV)
+            call("hdmoe_attn_bwd", dq, dk, dv, None, delta, go, out, q, k, v, lse, None, B, Sq, Skv, H, D, 0, 1)
+            for name, got, want in zip(("out", "lse", "dq", "dk", "dv"), (out, lse, dq, dk, dv), refs):
+                assert bool(torch.isfinite(got).all()), f"{name} (slow={slow}) not finite"
+                err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+                assert err < 2e-2, f"{name} (slow={slow}): {err:.3e}"            # bf16 probabilities / outputs (measured 2e-3 .. 1e-2)
+    finally:
+        os.environ.pop("HDMOE_ATTN_SLOW", None)
+
+
 def test_dispatch_plan_matches_reference_order():
     """Expert-contiguous, sample-stable permutation == concatenation of the reference's x[mask] per expert."""
     from hdmoe_hip import ops
