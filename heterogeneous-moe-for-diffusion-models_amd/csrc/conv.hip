@@ -1368,6 +1368,10 @@ int hdmoe_conv_wgrad(const void* x, const void* dy, float* const* G, const int* 
     const int rc = swg_try_launch(x, dy, G[0], N, H, W, Cin, Cout, kh[0], pt[0], pl[0], dtype, stream);
     if (rc <= 0) return rc;
   }
+  if (stride == 1 && !ones && ngroups == 1 && !seg && Ho == H && Wo == W && kh[0] == kw[0] && Cout <= 4) {
+    const int rc = towg_try_launch(x, dy, G[0], N, H, W, Cin, Cout, kh[0], pt[0], pl[0], dtype, stream);
+    if (rc <= 0) return rc;
+  }
   if (stride == 1 && !ones && maxtaps == 1 && Ho == H && Wo == W) {
     bool plain = true;
     for (int g = 0; g < ngroups; ++g) plain = plain && kh[g] == 1 && kw[g] == 1 && pt[g] == 0 && pl[g] == 0;

@@ -48,3 +48,6 @@ int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
                    hipStream_t stream);
 
+// k x k (k = 1 or 3) bf16 weight gradient for tiny output channel counts (Cout <= 4: output head, gate), one expert (lwgrad.hip).  Same return convention.
+int towg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
+                    hipStream_t stream);

@@ -281,7 +281,120 @@ __global__ __launch_bounds__(256) void swg_f32_kernel(SwgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k x k (k = 1 or 3) bf16 layers with a TINY output channel count (Cout <= 4: the output head 32 -> IN_in_channels 3x3 and the 2-way
+// gate 32 -> 2 1x1, reference model_config2.py output_proj / gate2).  The tiled kernel pads Cout to 32 rows per tap and took ~80 us
+// per layer on the serial tail of the step for 0.6 GFLOP; here it is plain vector arithmetic: thread = (channel pair of x, one of 16
+// pixel slices of an 8-row band), 9 x 4 x 2 fp32 accumulators, x straight from HBM (4 bytes per pixel-thread, 64 B per pixel over the
+// 16 lanes of a channel chunk), dy with its halo converted to fp32 [pixel][4] in LDS (one 16-byte broadcast read per tap).  The
+// slices meet by two cross-lane steps + LDS, one atomic flush of the <= 1152 words per workgroup.
+struct TowgArgs { const bf16* x; const bf16* dy; float* G; int N, H, W, Cin, Cout, pad, TH, tiles_y, ntiles, wshift; };
+
+template <int K>
+__global__ __launch_bounds__(256) void towg_bf16_kernel(TowgArgs a) {
+  constexpr int T = K * K;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  extern __shared__ __attribute__((aligned(16))) float tsm[];  // dy halo tile [(TH + K - 1)][(W + K - 1)][4], later the 4 waves' sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cp = tid & 15, sl = tid >> 4;
+  const int c0 = blockIdx.y * 32 + 2 * cp;
+  const int HWp = a.W + K - 1, HHp = a.TH + K - 1;
+  f2 acc[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[t][o] = (f2)(0.f);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int n = tile / a.tiles_y, y0 = (tile - n * a.tiles_y) * a.TH;
+    __syncthreads();                                          // the previous tile's readers are done
+    for (int e = tid; e < HHp * HWp; e += 256) {
+      const int hy = e / HWp, hx = e - hy * HWp;
+      const int iy = y0 + hy - a.pad, ix = hx - a.pad;
+      f32x4 v = (f32x4)(0.f);
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+        const bf16* d = a.dy + (((long)n * a.H + iy) * a.W + ix) * a.Cout;
+        for (int o = 0; o < a.Cout; ++o) v[o] = (float)d[o];
+      }
+      *reinterpret_cast<f32x4*>(tsm + 4 * e) = v;
+    }
+    __syncthreads();
+    const int rows = a.H - y0 < a.TH ? a.H - y0 : a.TH, npx = rows * a.W;
+    const bf16* xb = a.x + ((long)n * a.H + y0) * a.W * a.Cin + c0;
+#pragma unroll 2
+    for (int p = sl; p < npx; p += 16) {
+      const int y = a.wshift >= 0 ? p >> a.wshift : p / a.W, xx = p - y * a.W;
+      const unsigned xw = *reinterpret_cast<const unsigned*>(xb + (long)p * a.Cin);
+      const f2 xf = {__builtin_bit_cast(float, xw << 16), __builtin_bit_cast(float, xw & 0xFFFF0000u)};
+      // dW[tap][o][i] = sum_p' x[p'][i] dy[p' - tap + pad][o]: halo coordinates (y + 2 pad - ty, x + 2 pad - tx)
+      const float* dbase = tsm + 4 * ((y + K - 1) * HWp + xx + K - 1);
+#pragma unroll
+      for (int ty = 0; ty < K; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < K; ++tx) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(dbase - 4 * (ty * HWp + tx));
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[ty * K + tx][o] += xf * d[o];
+        }
+    }
+  }
+  // the 4 pixel slices of a wave (lanes with equal cp), then the 4 waves
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = acc[t][o][j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[t][o][j] = v;
+      }
+  __syncthreads();
+  if (lane < 16) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tsm[((wave * T + t) * 4 + o) * 32 + 2 * lane + j] = acc[t][o][j];
+  }
+  __syncthreads();
+  for (int e = tid; e < T * 4 * 32; e += 256) {
+    const int i = e & 31, o = (e >> 5) & 3, t = e >> 7;
+    if (o < a.Cout) {
+      const float v = tsm[e] + tsm[T * 128 + e] + tsm[2 * T * 128 + e] + tsm[3 * T * 128 + e];
+      atomicAdd(&a.G[((long)t * a.Cout + o) * a.Cin + blockIdx.y * 32 + i], v);
+    }
+  }
+}
+
 }  // namespace
+
+// k x k bf16 weight gradient for Cout <= 4 (k = 1 or 3, one expert, stride 1, "same" geometry): G [tap][Cout][Cin] += .  Same return convention.
+int towg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
+                    hipStream_t stream) {
+  static const bool off = getenv("HDMOE_TOWG") && atoi(getenv("HDMOE_TOWG")) == 0;
+  if (off || dtype != HDMOE_BF16 || Cout < 1 || Cout > 4 || Cin % 32 || (k != 1 && k != 3) || pt != (k - 1) / 2 || pl != (k - 1) / 2) return 1;
+  if (!x || !dy || !G || W > 256 || ((uintptr_t)x & 3)) return 1;
+  TowgArgs a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.G = G; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = (k - 1) / 2;
+  a.TH = H < 8 ? H : 8;
+  while (a.TH > 1 && (size_t)(a.TH + k - 1) * (W + k - 1) * 16 > 48 * 1024) a.TH >>= 1;
+  a.tiles_y = (H + a.TH - 1) / a.TH;
+  const long ntiles = (long)N * a.tiles_y;
+  if (ntiles >= (1l << 30)) return 1;
+  a.ntiles = (int)ntiles;
+  a.wshift = -1;
+  for (int sft = 0; sft < 9; ++sft) if ((1 << sft) == W) a.wshift = sft;
+  const int cb = Cin / 32;
+  long nb = 256 / cb; if (nb < 1) nb = 1;                    // ~one workgroup per CU: every workgroup ends with a flush of the same words
+  if (nb > ntiles) nb = ntiles;
+  const size_t halo = (size_t)(a.TH + k - 1) * (W + k - 1) * 16, red = (size_t)4 * k * k * 128 * 4;
+  const size_t lds = halo > red ? halo : red;
+  const dim3 grid((unsigned)nb, (unsigned)cb);
+  if (k == 3) hipLaunchKernelGGL(towg_bf16_kernel<3>, grid, dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(towg_bf16_kernel<1>, grid, dim3(256), lds, stream, a);
+  return hdmoe_launch_status();
+}
 
 // k x k fp32 layer with taps * Cin <= 64 (one expert, stride 1, "same" geometry): G [tap][Cout][Cin] += .  Same return convention.
 int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,

@@ -659,6 +659,29 @@ def test_mfma_attention_shift_paths_match_an_fp64_softmax(B, Sq, Skv, H, sq, sk,
         os.environ.pop("HDMOE_ATTN_SLOW", None)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(5, 32, 32, 32, 4, 3), (3, 32, 32, 32, 2, 1), (2, 12, 20, 64, 3, 3), (2, 5, 7, 32, 1, 1),
+                                              (300, 16, 16, 32, 4, 3)])
+def test_tiny_cout_weight_gradient(N, H, W, Cin, Cout, k):
+    """Output head (32 -> IN_in_channels, 3x3) and gate (32 -> 2, 1x1): the dedicated weight-gradient kernel (csrc/lwgrad.hip towg)
+    against torch's conv2d gradient on the bf16-rounded operands; odd image sizes, two channel chunks, many tiles per workgroup."""
+    from hdmoe_hip import ops
+    import torch.nn.functional as F
+    torch.manual_seed(N + H + Cout)
+    x = torch.randn(N, H, W, Cin).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5)
+    go = torch.randn(N, H, W, Cout).bfloat16()
+    xd = x.to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(DEV))
+    y = ops.mp_conv(xd, wd, 1.0, normalize=False)
+    y.backward(go.to(DEV))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    pad = (k - 1) // 2
+    yr = F.conv2d(F.pad(xr, (pad, k - 1 - pad, pad, k - 1 - pad)), wr)
+    yr.backward(go.float().permute(0, 3, 1, 2))
+    close_scaled(wd.grad, wr.grad, 5e-3, msg="dw")           # fp32 accumulation of exact bf16 products; the order differs
+
+
 def test_dispatch_plan_matches_reference_order():
     """Expert-contiguous, sample-stable permutation == concatenation of the reference's x[mask] per expert."""
     from hdmoe_hip import ops
