@@ -24,15 +24,15 @@
 
 namespace {
 
-template <int NT>
+template <int NT, bool P3>
 __global__ __launch_bounds__(64 * C6_NW) void conv6_split_kernel(C6SArgs sa) {
-  conv6s_body<NT>(sa, blockIdx.x, gridDim.x);
+  conv6s_body<NT, P3>(sa, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
 
 // x, y (and res) fp32; w = bf16 [hi | lo][g][tap][Cout][Cin] with `wplane_elems` elements between the two planes
-int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SPlan& plan) {
+int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SPlan& plan, bool p3) {
   static const bool off = getenv("HDMOE_CONV6") && atoi(getenv("HDMOE_CONV6")) == 0;
   if (off) return 1;
   if (c.stride != 1 || c.ones || c.Cphys != c.Cin || c.Ipad != c.Cin || c.Cin % 32 || c.Cout % 32 || c.Cstore != c.Cout) return 1;
@@ -46,7 +46,8 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   C6Args& a = sa.c;
   a.x = c.x; a.w = c.w; a.y = c.y; a.res = c.res; a.seg = c.seg; a.wstride = c.wstride;
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.ngroups = c.ngroups; a.alpha = c.alpha; a.beta = c.beta;
-  a.xbytes = (int)xbytes; a.wbytes = (int)wbytes; a.dbg = 0; a.stamps = nullptr;
+  static const int dbg = getenv("HDMOE_C6S_DBG") ? atoi(getenv("HDMOE_C6S_DBG")) : 0;   // development ablations (conv6s_body.h): 1 no MFMA, 2 no in-loop DMA, 4 no stores, 8 no halo conversion
+  a.xbytes = (int)xbytes; a.wbytes = (int)wbytes; a.dbg = dbg; a.stamps = nullptr;
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.ks[g] = c.kh[g]; a.pt[g] = c.pt[g]; a.pl[g] = c.pl[g]; a.order[g] = g; }
   a.TW = c.W >= 32 ? 32 : 16; a.tws = a.TW == 32 ? 5 : 4; a.TH = 256 / a.TW;
   a.tiles_x = c.W / a.TW;
@@ -60,10 +61,12 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   int T = 0;
   const int tab_bytes = (fuse && fuse->in_scale) ? 16 * c.Cin : 0;   // scale / shift table of the fused input transform (conv6s_body.h)
   if (tab_bytes && c.Cin > 512) return 1;
+  // p3 (the stand-alone forward kernel): a weight stage holds the hi and the lo image of its taps (conv6s_body.h P3)
+  const int planes = p3 ? 2 : 1;
   for (int t = 9; t >= 3; --t)
-    if (t * (NB / 16) <= 40 && 2 * a.hb_bytes + 2 * t * NB * 64 + tab_bytes <= LDS_CAP && (t == 9 || t == 5 || t == 3)) { T = t; break; }
+    if (t * (NB / 16) <= 40 && 2 * a.hb_bytes + 2 * planes * t * NB * 64 + tab_bytes <= LDS_CAP && (t == 9 || t == 5 || t == 3)) { T = t; break; }
   if (!T) return 1;
-  a.T = T; a.wb_bytes = T * NB * 64;
+  a.T = T; a.wb_bytes = planes * T * NB * 64;
   auto recip = [](int d) { return (unsigned)((1ull << 32) / (unsigned)d + 1); };
   a.m_nblk = a.nblk == 1 ? 0xFFFFFFFFu : recip(a.nblk); a.m_T = recip(T); a.m_tpi = a.tpi == 1 ? 0xFFFFFFFFu : recip(a.tpi);
   a.m_tx = a.tiles_x == 1 ? 0xFFFFFFFFu : recip(a.tiles_x);
@@ -84,15 +87,23 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
 }
 
 int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, hipStream_t stream) {
+  static const bool p3 = !(getenv("HDMOE_C6S_P3") && atoi(getenv("HDMOE_C6S_P3")) == 0);   // 0: the three products as separate passes (A/B)
   C6SPlan plan;
-  if (conv6s_plan(c, wplane_elems, fuse, plan)) return 1;
+  if (conv6s_plan(c, wplane_elems, fuse, plan, p3)) return 1;
   static bool attr_set = false;
   if (!attr_set) {
     attr_set = true;
-    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (plan.NT == 2) hipLaunchKernelGGL(conv6_split_kernel<2>, dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
-  else hipLaunchKernelGGL(conv6_split_kernel<1>, dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+  if (p3) {
+    if (plan.NT == 2) hipLaunchKernelGGL((conv6_split_kernel<2, true>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+    else hipLaunchKernelGGL((conv6_split_kernel<1, true>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+  } else {
+    if (plan.NT == 2) hipLaunchKernelGGL((conv6_split_kernel<2, false>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+    else hipLaunchKernelGGL((conv6_split_kernel<1, false>), dim3(plan.G), dim3(64 * C6_NW), plan.lds, stream, plan.sa);
+  }
   return hdmoe_launch_status();
 }

@@ -14,11 +14,15 @@ struct C6SArgs {
 struct C6SPlan { C6SArgs sa; int NT; unsigned G; size_t lds; };
 struct ConvFuse;
 // Launch geometry of the split-bf16 conv for one layer (conv6s.hip).  0 = planned, 1 = outside its domain.
-int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SPlan& plan);
+int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SPlan& plan, bool p3 = false);
 
 namespace {
 
-template <int NT>
+// P3: the three products of a split-bf16 step share ONE pass over the weight stages -- a stage holds the hi AND the lo weight image of
+// its taps, a k-step loads x_hi, x_lo, w_hi, w_lo once and issues w_hi x_hi + w_lo x_hi + w_hi x_lo back to back: 8 fragment reads per
+// 12 MFMAs instead of 12, a third of the stage barriers (round 3; the forward trunk convs).  Without P3 the products are separate
+// passes (sa.nprod of them: the bf16-operand backward runs ONE).
+template <int NT, bool P3 = false>
 DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
 #if __HIP_DEVICE_COMPILE__
   const C6Args& a = sa.c;
@@ -159,8 +163,10 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
   // ---- weights (as conv6.hip; plane = 0 hi / 1 lo)
   const unsigned wlo = (unsigned)((((wave / PPT) * a.Cout + (wave % PPT) * 16 + prow) * a.Cin) * 2 + csl);
   const int wkstep = (NW / PPT) * a.Cout * a.Cin * 2;
+  const int wb_half = a.wb_bytes >> 1;                               // P3: [hi taps | lo taps] inside one weight buffer
   auto issue_wpiece = [&](int sb, int k, int wbo) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(lds + wbo + (wave + NW * k) * 1024), 16, wlo, sb + k * wkstep, 0, 0);
+    if (P3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(lds + wbo + wb_half + (wave + NW * k) * 1024), 16, wlo, sb + sa.wplane + k * wkstep, 0, 0);
   };
   auto wpieces = [&](int ntl) { return max(0, (ntl - wave / PPT + (NW / PPT) - 1) / (NW / PPT)); };
   auto stage_base = [&](int wbase, int plane, int c, int t0) { return wbase + plane * sa.wplane + (t0 * a.Cout * a.Cin + c * 32) * 2; };
@@ -207,7 +213,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
     for (int c = 0; c < nchunks; ++c) {
       const bool last_chunk = c == nchunks - 1;
       const bool more = !last_chunk || has_next;                    // another halo chunk follows (this unit's or the next unit's)
-      const int lastp = sa.nprod - 1;                               // nprod = 1: x_hi * w_hi only (plain bf16 operands, the trunk BACKWARD)
+      const int lastp = P3 ? 0 : sa.nprod - 1;                      // nprod = 1: x_hi * w_hi only (plain bf16 operands, the trunk BACKWARD)
       for (int prod = 0; prod <= lastp; ++prod) {                   // x_hi * w_hi, x_hi * w_lo, x_lo * w_hi
         const int xoff = prod == 2 ? a.hb_bytes : 0;
         int ky = 0, kx = 0;
@@ -232,13 +238,14 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
             if (last_chunk) { plan(nu, hoc); halo_load(hoc, 0, rh, nhp_of(nu.ppt)); tab_load(nu); }   // (cur's own offsets are no longer needed)
             else halo_load(hoc, c + 1, rh, nhp_of(cur.ppt));
           }
-          auto side = [&](int k) { if (k < NWP && k < nwp) issue_wpiece(nsb, k, wbn); };
+          auto side = [&](int k) { if (k < NWP && k < nwp && !(a.dbg & 2)) issue_wpiece(nsb, k, wbn); };
           // ---- MFMA over the stage's taps (structure of conv6.hip)
           const int hbpx = xoff >> 6;
           const unsigned char* wb = lds + WB0 + sp * a.wb_bytes;
           // software pipeline at k-step granularity (two per tap; a tap-deep pipeline as in conv6.hip needs 32 more registers than
           // this kernel has beside the fp32 halo registers): set A always holds a tap's first 16 channels, set B its second
           bf16x8 fxA[MB], fwA[NT], fxB[MB], fwB[NT];
+          bf16x8 lxA[P3 ? MB : 1], lwA[P3 ? NT : 1], lxB[P3 ? MB : 1], lwB[P3 ? NT : 1];   // P3: the lo fragments of the same k-step
           int ad[MB];
           auto tap_addr = [&]() {
             const int toff = ky * cur.HWp + kx + hbpx;
@@ -249,37 +256,49 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
             }
             if (++kx == cur.ks) { kx = 0; ++ky; }
           };
-          auto load_k = [&](bf16x8 (&fx)[MB], bf16x8 (&fw)[NT], int tl, int s2) {
+          auto load_k = [&](bf16x8 (&fx)[MB], bf16x8 (&fw)[NT], bf16x8 (&lx)[P3 ? MB : 1], bf16x8 (&lw)[P3 ? NT : 1], int tl, int s2) {
             const unsigned char* wt = wb + tl * NB * 64;
 #pragma unroll
-            for (int m = 0; m < MB; ++m) fx[m] = *reinterpret_cast<const bf16x8*>(lds + (ad[m] ^ (s2 << 5)));
+            for (int m = 0; m < MB; ++m) {
+              fx[m] = *reinterpret_cast<const bf16x8*>(lds + (ad[m] ^ (s2 << 5)));
+              if (P3) lx[m] = *reinterpret_cast<const bf16x8*>(lds + a.hb_bytes + (ad[m] ^ (s2 << 5)));
+            }
 #pragma unroll
-            for (int b = 0; b < NT; ++b) fw[b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ (s2 << 5)));
+            for (int b = 0; b < NT; ++b) {
+              fw[b] = *reinterpret_cast<const bf16x8*>(wt + b * 2048 + (wl ^ (s2 << 5)));
+              if (P3) lw[b] = *reinterpret_cast<const bf16x8*>(wt + wb_half + b * 2048 + (wl ^ (s2 << 5)));
+            }
           };
-          auto mm = [&](const bf16x8 (&fx)[MB], const bf16x8 (&fw)[NT], bool first) {
+          auto mm = [&](const bf16x8 (&fx)[MB], const bf16x8 (&fw)[NT], const bf16x8 (&lx)[P3 ? MB : 1], const bf16x8 (&lw)[P3 ? NT : 1], bool first) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
               for (int b = 0; b < NT; ++b)
-                if ((m + b == 0) == first) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], fx[m], acc[m][b], 0, 0, 0);
+                if ((m + b == 0) == first && !(a.dbg & 1)) {
+                  acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], fx[m], acc[m][b], 0, 0, 0);
+                  if (P3) {
+                    acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lw[b], fx[m], acc[m][b], 0, 0, 0);
+                    acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], lx[m], acc[m][b], 0, 0, 0);
+                  }
+                }
           };
           tap_addr();
-          load_k(fxA, fwA, 0, 0);
+          load_k(fxA, fwA, lxA, lwA, 0, 0);
 #pragma unroll
           for (int tl = 0; tl < C6_MAXT; ++tl) {
             if (tl < ntl) {
-              mm(fxA, fwA, true);
+              mm(fxA, fwA, lxA, lwA, true);
               __builtin_amdgcn_sched_barrier(0);
-              load_k(fxB, fwB, tl, 1);
+              load_k(fxB, fwB, lxB, lwB, tl, 1);
               side(tl);
               __builtin_amdgcn_sched_barrier(0);
-              mm(fxA, fwA, false);
-              mm(fxB, fwB, true);
+              mm(fxA, fwA, lxA, lwA, false);
+              mm(fxB, fwB, lxB, lwB, true);
               __builtin_amdgcn_sched_barrier(0);
               tap_addr();                                           // (runs one tap past the stage's last: read inside the buffer, never used)
-              load_k(fxA, fwA, min(tl + 1, ntl - 1), 0);
+              load_k(fxA, fwA, lxA, lwA, min(tl + 1, ntl - 1), 0);
               __builtin_amdgcn_sched_barrier(0);
-              mm(fxB, fwB, false);
+              mm(fxB, fwB, lxB, lwB, false);
             } else {
               side(tl);
             }
@@ -291,8 +310,10 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
       if (more) {
         if (last_chunk) tab_store();                                // the next unit's scale / shift table (visible after the barrier)
         __syncthreads();                                            // every wave is done reading this chunk's hi / lo images
-        if (last_chunk) halo_store(nu, hoc, 0, rh);
-        else halo_store(cur, hoc, c + 1, rh);
+        if (!(a.dbg & 8)) {
+          if (last_chunk) halo_store(nu, hoc, 0, rh);
+          else halo_store(cur, hoc, c + 1, rh);
+        }
       }
     }
     // ---- epilogue: fp32, one 16-byte store per accumulator quad (4 consecutive channels of the lane's pixel)
@@ -316,7 +337,7 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
             f4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = a.alpha * acc[m][b][4 * i + e];
-            if (ok) {
+            if (ok && !(a.dbg & 4)) {
               if (R) { const f4 rv = *reinterpret_cast<const f4*>(R + pix + 32 * b + 8 * i); v += a.beta * rv; }
               *reinterpret_cast<f4*>(Y + pix + 32 * b + 8 * i) = v;
 #pragma unroll

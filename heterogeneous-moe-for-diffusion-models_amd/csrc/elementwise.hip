@@ -118,6 +118,35 @@ __global__ void scale_rows_bwd_kernel(T* dx, float* ds, const T* dy, const T* x,
   }
 }
 
+template <typename T>
+__global__ void scale_rows_bwd_vec_kernel(T* dx, float* ds, const T* dy, const T* x, const float* s, long Lv, int chunk) {
+  constexpr int W = VT<T>::W;
+  __shared__ float sm[16];
+  const int r = blockIdx.y;
+  const long p0 = (long)blockIdx.x * chunk;
+  const long p1 = (p0 + chunk < Lv) ? p0 + chunk : Lv;
+  const float sv = s[r];
+  float acc = 0.f;
+  for (long i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+    float g[W], xv[W];
+    vload<T>(g, dy + ((long)r * Lv + i) * W);
+    if (ds) {
+      vload<T>(xv, x + ((long)r * Lv + i) * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc += g[j] * xv[j];
+    }
+    if (dx) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) g[j] *= sv;
+      vstore<T>(dx + ((long)r * Lv + i) * W, g);
+    }
+  }
+  if (ds) {
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(&ds[r], acc);
+  }
+}
+
 // ---------------------------------------------------------------- mp_cat  (model_internals.py:69-92)
 template <typename T>
 __global__ void cat2_fwd_kernel(T* out, const T* a, const T* b, float wa, float wb, int Ca, int Cb, long rows) {
@@ -247,6 +276,23 @@ __global__ void lerp_param_bwd_kernel(T* da, T* db, float* dalpha, const T* g, c
     da[i] = from_f<T>((1.f - al) * gv);
     db[i] = from_f<T>(al * gv);
     acc += gv * (to_f(b[i]) - to_f(a[i]));
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(dalpha, acc);
+}
+
+template <typename T>
+__global__ void lerp_param_bwd_vec_kernel(T* da, T* db, float* dalpha, const T* g, const T* a, const T* b, const float* alpha, long nv) {
+  constexpr int W = VT<T>::W;
+  __shared__ float sm[16];
+  const float al = *alpha;
+  float acc = 0.f;
+  GRID_STRIDE(v, nv) {
+    float gv[W], av[W], bv[W], o1[W], o2[W];
+    vload<T>(gv, g + v * W); vload<T>(av, a + v * W); vload<T>(bv, b + v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) { o1[j] = (1.f - al) * gv[j]; o2[j] = al * gv[j]; acc += gv[j] * (bv[j] - av[j]); }
+    vstore<T>(da + v * W, o1); vstore<T>(db + v * W, o2);
   }
   acc = block_sum(acc, sm);
   if (threadIdx.x == 0) atomicAdd(dalpha, acc);
@@ -960,7 +1006,12 @@ int hdmoe_scale_rows_bwd(void* dx, float* ds, const void* dy, const void* x, con
   if (rows > 65535) return HDMOE_EINVAL;
   const int chunk = 8192;
   dim3 grid(cdiv(L, chunk), (unsigned)rows);
-  DT_SWITCH(dtype, hipLaunchKernelGGL(scale_rows_bwd_kernel<T>, grid, dim3(TPB), 0, stream, (T*)dx, ds, (const T*)dy,
+  DT_SWITCH(dtype, if (L % VT<T>::W == 0 && al16(dx) && al16(dy) && al16(x)) {
+                     const long Lv = L / VT<T>::W;
+                     const int vchunk = 2048;                    // 16-byte vectors per workgroup: 8 per thread
+                     hipLaunchKernelGGL(scale_rows_bwd_vec_kernel<T>, dim3(cdiv(Lv, vchunk), (unsigned)rows), dim3(TPB), 0, stream, (T*)dx, ds,
+                                        (const T*)dy, (const T*)x, s, Lv, vchunk);
+                   } else hipLaunchKernelGGL(scale_rows_bwd_kernel<T>, grid, dim3(TPB), 0, stream, (T*)dx, ds, (const T*)dy,
                                       (const T*)x, s, L, chunk))
 }
 int hdmoe_cat2_fwd(void* out, const void* a, const void* b, float wa, float wb, int Ca, int Cb, long rows, int dtype,
@@ -1014,7 +1065,11 @@ int hdmoe_lerp_param_fwd(void* out, const void* a, const void* b, const float* a
 }
 int hdmoe_lerp_param_bwd(void* da, void* db, float* dalpha, const void* g, const void* a, const void* b,
                          const float* alpha, long n, int dtype, hipStream_t stream) {
-  DT_SWITCH(dtype, L1D(lerp_param_bwd_kernel<T>, n, (T*)da, (T*)db, dalpha, (const T*)g, (const T*)a, (const T*)b, alpha, n))
+  DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(da) && al16(db) && al16(g) && al16(a) && al16(b)) {
+                     long blocks = (n / VT<T>::W + TPB - 1) / TPB; if (blocks > 1024) blocks = 1024;   // (one atomic per block)
+                     hipLaunchKernelGGL(lerp_param_bwd_vec_kernel<T>, dim3((unsigned)blocks), dim3(TPB), 0, stream, (T*)da, (T*)db, dalpha, (const T*)g,
+                                        (const T*)a, (const T*)b, alpha, n / VT<T>::W);
+                   } else L1D(lerp_param_bwd_kernel<T>, n, (T*)da, (T*)db, dalpha, (const T*)g, (const T*)a, (const T*)b, alpha, n))
 }
 int hdmoe_gate_mix_fwd(void* out, float* gate, const void* logits, const void* U, const void* A, long rows, int C,
                        int dtype, hipStream_t stream) {

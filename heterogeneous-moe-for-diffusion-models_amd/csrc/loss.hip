@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void edm_loss_reduce_kernel(float* out, float*
   den = block_sum(den, sm) / (float)B;
   zu = block_sum(zu, sm) / (float)B;
   zv = block_sum(zv, sm) / (float)B;
-  if (tid < E) {
+  // column means of the gate probabilities: every thread takes rows tid, tid + 256, ... of one column at a time (a lone thread per
+  // column walked B dependent loads: 36 us on the serial tail of the step); fixed order, no atomics
+  for (int e = 0; e < E; ++e) {
     float a = 0.f, c = 0.f;
-    for (int b = 0; b < B; ++b) { a += pU[(long)b * E + tid]; c += pV[(long)b * E + tid]; }
-    colU[tid] = a / (float)B; colV[tid] = c / (float)B;
-    aux[tid] = colU[tid]; aux[E + tid] = colV[tid];
+    for (int b = tid; b < B; b += blockDim.x) { a += pU[(long)b * E + e]; c += pV[(long)b * E + e]; }
+    a = block_sum(a, sm); c = block_sum(c, sm);
+    if (tid == 0) { colU[e] = a / (float)B; colV[e] = c / (float)B; aux[e] = colU[e]; aux[E + e] = colV[e]; }
   }
   __syncthreads();
   if (tid == 0) {

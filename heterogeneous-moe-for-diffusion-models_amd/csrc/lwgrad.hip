@@ -374,11 +374,12 @@ int towg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W
                     hipStream_t stream) {
   static const bool off = getenv("HDMOE_TOWG") && atoi(getenv("HDMOE_TOWG")) == 0;
   if (off || dtype != HDMOE_BF16 || Cout < 1 || Cout > 4 || Cin % 32 || (k != 1 && k != 3) || pt != (k - 1) / 2 || pl != (k - 1) / 2) return 1;
-  if (!x || !dy || !G || W > 256 || ((uintptr_t)x & 3)) return 1;
+  if (!x || !dy || !G || ((uintptr_t)x & 3)) return 1;
   TowgArgs a;
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.G = G; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = (k - 1) / 2;
   a.TH = H < 8 ? H : 8;
   while (a.TH > 1 && (size_t)(a.TH + k - 1) * (W + k - 1) * 16 > 48 * 1024) a.TH >>= 1;
+  if ((size_t)(a.TH + k - 1) * (W + k - 1) * 16 > 48 * 1024) return 1;
   a.tiles_y = (H + a.TH - 1) / a.TH;
   const long ntiles = (long)N * a.tiles_y;
   if (ntiles >= (1l << 30)) return 1;
