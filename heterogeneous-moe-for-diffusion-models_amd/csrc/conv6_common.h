@@ -17,6 +17,7 @@ struct C6Args {
   int nblk;                           // output-channel blocks
   int hb_bytes, wb_bytes;             // bytes of one halo buffer / one weight buffer
   int xbytes, wbytes;                 // extents of x and of the weight image (buffer descriptors; < 4 GB)
+  unsigned ybytes;                    // extent of y for buffer-descriptor stores with a counted drain (conv6_body.h epilogue); 0: plain stores
   unsigned m_nblk, m_T, m_tpi, m_tx;  // 2^32 / d + 1 reciprocals of nblk, T, tpi, tiles_x
   int w_rowpitch, w_tapstride;        // weight image geometry in elements: between consecutive output rows / consecutive taps (default Cin, Cout * Cin);
                                       // larger values read a [tap][rows][pitch] image with more channels / rows than this conv uses

@@ -74,6 +74,11 @@ int conv6s_plan(const ConvArgs& c, long wplane_elems, const ConvFuse* fuse, C6SP
   sa.in_scale = fuse ? fuse->in_scale : nullptr; sa.in_shift = fuse ? fuse->in_shift : nullptr; sa.in_relu = fuse ? fuse->in_relu : 0;
   sa.stats = fuse ? fuse->stats : nullptr;
   sa.nprod = 3;
+  {
+    static const bool drain = getenv("HDMOE_C6S_COUNTED") && atoi(getenv("HDMOE_C6S_COUNTED")) == 0;   // 0: plain stores, full drain (A/B)
+    const long yb = (long)c.N * c.H * c.W * c.Cout * 4;
+    a.ybytes = (yb < (1l << 32) && !drain) ? (unsigned)yb : 0u;
+  }
   const size_t lds = 2 * (size_t)a.hb_bytes + 2 * (size_t)a.wb_bytes + tab_bytes;
   const long tiles = (long)c.N * a.tpi;
   long ub = ((tiles + 1) / 2 + c.ngroups) * a.nblk;

@@ -37,6 +37,11 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
   const int prow = lane >> 2;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
+  // y through a buffer descriptor too: a store whose pixel is outside the image gets an out-of-range offset and is dropped by the
+  // hardware, so every wave issues the SAME number of store instructions per unit -- which lets the next unit's first barrier wait
+  // with a counted vmcnt for the weight DMA issued BEFORE those stores instead of draining them (ybytes == 0: plain stores, full drain)
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+  int pending = 0;                                                   // store instructions of the previous unit's epilogue still in flight
 
   // ---- unit list (see conv6.hip): slot oi of the descending-kernel-size group list lives in lane oi
   const int oi_l = lane & 7;
@@ -221,7 +226,10 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
           const int t0 = tg * a.T;
           const int ntl = min(a.T, cur.ntaps - t0);
           const bool last_stage = prod == lastp && tg + 1 == cur.ntg;
-          __syncthreads();
+          // vmcnt counts in issue order: the DMA of this stage is older than the epilogue stores of the previous unit
+          if (pending == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else __syncthreads();
+          pending = 0;
           // ---- next stage's weights
           const int wbn = WB0 + (sp ^ 1) * a.wb_bytes;
           int nsb = 0, nwp = 0;
@@ -324,6 +332,8 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
       const int ty0 = tile_w ? cur.ty0[1] : cur.ty0[0], tx0 = tile_w ? cur.tx0[1] : cur.tx0[0];
       const bool tv = tile_w ? cur.valid[1] : cur.valid[0];
       float s1 = 0.f, s2 = 0.f;
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      const bool counted = a.ybytes != 0 && !R && !(a.dbg & 4) && MB * NT * 4 == 16;
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const int q = ((mb0 + m) & 7) * 32 + r;
@@ -337,7 +347,13 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
             f4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = a.alpha * acc[m][b][4 * i + e];
-            if (ok && !(a.dbg & 4)) {
+            if (counted) {                                         // (no residual on this path)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ok ? (unsigned)((pix + 32 * b + 8 * i) * 4) : 0xFFFFFFFFu, 0, 0);
+              if (ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+              }
+            } else if (ok && !(a.dbg & 4)) {
               if (R) { const f4 rv = *reinterpret_cast<const f4*>(R + pix + 32 * b + 8 * i); v += a.beta * rv; }
               *reinterpret_cast<f4*>(Y + pix + 32 * b + 8 * i) = v;
 #pragma unroll
@@ -356,6 +372,8 @@ DEVI void conv6s_body(const C6SArgs& sa, const int bid, const int G) {
           sa.stats[2 * slot] = s1; sa.stats[2 * slot + 1] = s2;
         }
       }
+      // (a LOWER bound of the instructions issued after the DMA is what the counted wait needs: the statistics stores are not counted)
+      pending = counted ? 16 : 0;
     }
     if (!has_next) break;
     cur = nu;
