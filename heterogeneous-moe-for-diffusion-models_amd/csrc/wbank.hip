@@ -16,15 +16,37 @@ struct __attribute__((aligned(8))) WBDesc {   // mirrored byte-for-byte by hdmoe
 
 template <typename T> DEVI void wb_store(void* base, long idx, float v) { ((T*)base)[idx] = from_f<T>(v); }
 
+constexpr int WB_PREP_ROW = 3200;            // rows up to this many elements are normalised in registers + LDS (one global read of the row)
+
 __global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, const int2* rows, int mutate) {
   __shared__ float sm[16];
+  __shared__ float rowl[WB_PREP_ROW];
   const int2 ro = rows[blockIdx.x];
   const WBDesc d = descs[ro.x];
   const int o = ro.y, tid = threadIdx.x;
   const int taps = d.kh * d.kw, fan = d.I * taps;
   float* w = (float*)d.w_raw + (long)o * fan;
+  const bool cached = fan <= WB_PREP_ROW;      // (uniform over the block)
   float scale = 1.f;
-  if (d.normalize) {
+  if (cached) {
+    // one pass over HBM: the row sits in LDS from here on (before: norm pass, in-place rewrite, second norm pass and a strided image
+    // pass each paid a global round trip -- 127 us for the model's ~35 k rows, serial at the head of every training step)
+    float ss = 0.f;
+    for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; rowl[e] = v; ss += v * v; }
+    if (d.normalize) {
+      const float c = rsqrtf((float)fan);
+      ss = block_sum(ss, sm);
+      float inv = 1.f / (1e-4f + sqrtf(ss) * c);
+      if (mutate && d.mutate_ok) {
+        float s2 = 0.f;
+        for (int e = tid; e < fan; e += blockDim.x) { const float v = rowl[e] * inv; rowl[e] = v; w[e] = v; s2 += v * v; }
+        s2 = block_sum(s2, sm);
+        inv = 1.f / (1e-4f + sqrtf(s2) * c);
+      }
+      scale = inv * d.gain * c;
+    }
+    __syncthreads();
+  } else if (d.normalize) {
     const float c = rsqrtf((float)fan);
     float ss = 0.f;
     for (int e = tid; e < fan; e += blockDim.x) { const float v = w[e]; ss += v * v; }
@@ -41,11 +63,11 @@ __global__ __launch_bounds__(128) void wbank_prep_kernel(const WBDesc* descs, co
     scale = inv * d.gain * c;
   }
   const bool f32 = d.dtype == HDMOE_F32;
-  // image pass in (tap, input channel) order: the forward image [tap][O][Ipad] is written in runs of I consecutive elements (the row
-  // itself, read with stride taps, is 1-25 KB and sits in L1 / L2 after the norm passes); only the flipped image stays scattered
+  // image pass in (tap, input channel) order: the forward image [tap][O][Ipad] is written in runs of I consecutive elements; only the
+  // flipped image stays scattered
   for (int e2 = tid; e2 < fan; e2 += blockDim.x) {
     const int t = e2 / d.I, i = e2 - t * d.I;
-    const float v = w[i * taps + t] * scale;
+    const float v = (cached ? rowl[i * taps + t] : w[i * taps + t]) * scale;
     const long fi = ((long)t * d.O + o) * d.Ipad + i;
     const long di = ((long)(taps - 1 - t) * d.I + i) * d.Opad + o;
     if (f32) { wb_store<float>((void*)d.wf, fi, v); if (d.wd) wb_store<float>((void*)d.wd, di, v); }
