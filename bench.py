@@ -144,6 +144,8 @@ def roofline_leg(step_fn, n_steps):
             a["n"] += 1
     # v_exp_f32 issues at 8 cycles per wave-instruction (MI355X_MICROARCH.md): 1024 SIMDs x 64 lanes / 8 cycles x 2.4 GHz exps per second.
     # The forward evaluates one exp per (query, key, head) pair; the backward recomputes the probabilities in both of its kernels (dq; dk + dv).
+    # (measured on these kernels with SQ_ACTIVE_INST_VALU at a 2.08 GHz clock: ~16 VALU-active cycles per v_exp_f32 wave instruction --
+    #  against THAT rate the forward is at ~75 %, the backward kernels at 80-90 % of their instruction-issue floors)
     exp_peak = 1024 * 64 / 8 * 2.4e9
     rep = []
     for key, t in sorted(attn.items(), key=lambda kv: -sum(kv[1]["ms"])):
