@@ -41,7 +41,7 @@ int conv6_split_try_launch(const ConvArgs& a, long wplane_elems, const ConvFuse*
 int lwg_try_launch(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, long HW, int Cin, int Cout,
                    int dtype, hipStream_t stream);
 
-// Pointwise forward / dgrad with Cin >= 1024 and Cout <= 64 (kgemm.hip).  Same return convention.
+// Pointwise forward / dgrad with Cin >= 512 and Cout <= 64 (kgemm.hip).  Same return convention.
 int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 
 // k x k fp32 weight gradient for tiny input channel counts (taps * Cin <= 64: the stem), one expert (lwgrad.hip).  Same return convention.

@@ -1,5 +1,5 @@
 // Pointwise forward / dgrad with a LONG contraction and few outputs: y[m][o] = alpha * sum_k x[m][k] * w[o][k] + beta * res[m][o],
-// K = Cin >= 1024, Cout <= 64, one expert.  These are the ViT experts' patch embedding (K = C * p^2 up to 8192 input features per
+// K = Cin >= 512 (HDMOE_KGEMM_MINK), Cout <= 64, one expert.  These are the ViT experts' patch embedding (K = C * p^2 up to 8192 input features per
 // token, reference models/model_components.py:670-679) and the input gradient of unpatch_proj (:700-706).  The general 1x1 path
 // (conv.hip: conv_fwd5) tiles positions and walks K inside one workgroup: with 2048 tokens that is 8 workgroups on a 256-CU chip
 // (285 us for a 33 MB read).  Here both operands are K-contiguous in memory, so MFMA fragments are plain 16-byte global loads (no
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512) void kgemm_kernel(KArgs a) {
 int kgemm_try_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
   static const bool off = getenv("HDMOE_KGEMM") && atoi(getenv("HDMOE_KGEMM")) == 0;
   if (off || dtype != HDMOE_BF16 || a.ngroups != 1 || a.seg || a.stride != 1 || a.ones || a.kh[0] != 1 || a.kw[0] != 1 || a.pt[0] || a.pl[0]) return 1;
-  if (a.Cin != a.Cphys || a.Ipad != a.Cin || a.Cin % 64 || a.Cin < 1024 || a.Cout != a.Cstore || a.Cout % 32 || a.Cout > 64) return 1;
+  static const int mink = getenv("HDMOE_KGEMM_MINK") ? atoi(getenv("HDMOE_KGEMM_MINK")) : 512;   // (768: the text projections of the fusion cross-attention, 37 + 31 -> ~2 x 12 us on the serial stage; same-box step -0.1 ms)
+  if (a.Cin != a.Cphys || a.Ipad != a.Cin || a.Cin % 64 || a.Cin < mink || a.Cout != a.Cstore || a.Cout % 32 || a.Cout > 64) return 1;
   if (a.Ho != a.H || a.Wo != a.W || (((uintptr_t)a.x | (uintptr_t)a.w) & 15)) return 1;
   KArgs k;
   k.x = (const bf16*)a.x; k.w = (const bf16*)a.w; k.y = (bf16*)a.y; k.res = (const bf16*)a.res;
