@@ -1256,6 +1256,10 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     const int rc = kgemm_try_launch(a, dtype, stream);
     if (rc <= 0) return rc;
   }
+  {                                                        // grouped fp32 linear on one-position rows, long input (mlinear.hip)
+    const int rc = glin_try_launch(a, dtype, stream);
+    if (rc <= 0) return rc;
+  }
   if (stride == 1 && (long)Ho * Wo >= 64) {
     // ---- v2: LDS-staged 256-pixel tiles
     const int PT = 4 * CV2_MT * 32;

@@ -51,3 +51,6 @@ int swg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W,
 // k x k (k = 1 or 3) bf16 weight gradient for tiny output channel counts (Cout <= 4: output head, gate), one expert (lwgrad.hip).  Same return convention.
 int towg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W, int Cin, int Cout, int k, int pt, int pl, int dtype,
                     hipStream_t stream);
+
+// Grouped fp32 linear on one-position rows with a long input, 256 <= Cin <= 1024 (the experts' text projection; mlinear.hip).  Same return convention.
+int glin_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);

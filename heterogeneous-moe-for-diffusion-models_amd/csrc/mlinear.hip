@@ -7,7 +7,9 @@
 //   dx[r][i]   = sum_l sum_o dy_l[r][o] * W_l,g(r)[o][i]     (also the sum over the layers that autograd would do with L - 1 adds)
 //   dW_l,g[o][i] += sum_{r in g} dy_l[r][o] * x[r][i]        (one owner thread per element: no atomics, deterministic)
 // fp32 FMA code on purpose: the whole family is ~100 MFLOP per step and lives on the fp32 vector path.
+#include <stdlib.h>
 #include "common.h"
+#include "conv_args.h"
 #include "hdmoe.h"
 
 namespace {
@@ -122,6 +124,74 @@ __global__ __launch_bounds__(256) void mlin_wgrad_kernel(MLArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ONE grouped fp32 linear layer with a LONG input (the experts' text projection, 768 -> emb_size, reference model_components.py:261
+// map_text: rows = routed samples, one position each).  hdmoe_conv_fwd sent it to the one-row-per-block kernel of conv.hip (92 us on
+// the U-Net branch's chain, 62 us on the ViT branch's).  Here a wave owns four consecutive rows and a quarter of the outputs: the rows
+// sit in registers (I / 64 floats per lane and row), a weight row is ONE coalesced read per 256 inputs shared by the four rows, the four
+// dot products meet by cross-lane adds.
+struct GLArgs { const float* x; const float* w; float* y; const float* res; const int* seg; long wstride; int R, I, Ipad, O, ngroups; float alpha, beta; };
+
+template <int NJ>                                             // NJ = ceil(I / 256) float4 pieces per lane and row
+__global__ __launch_bounds__(256) void glin_f32_kernel(GLArgs a) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 4;
+  int g[4];
+  f4 xv[4][NJ];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + k;
+    g[k] = -1;
+    if (r < a.R) {
+      if (!a.seg) g[k] = 0;
+      else for (int i = 0; i < a.ngroups; ++i) if (r >= a.seg[i] && r < a.seg[i + 1]) g[k] = i;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = 4 * lane + 256 * j;
+      xv[k][j] = (g[k] >= 0 && i < a.I) ? *reinterpret_cast<const f4*>(a.x + (long)r * a.I + i) : (f4)(0.f);
+    }
+  }
+  const bool same = g[0] == g[1] && g[1] == g[2] && g[2] == g[3];   // (rows are sorted by group: true except at a segment boundary)
+  const int oq = (a.O + 3) / 4, o0 = wave * oq, o1 = min(a.O, o0 + oq);
+  for (int o = o0; o < o1; ++o) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (same) {
+      if (g[0] >= 0) {
+        const float* wr = a.w + (long)g[0] * a.wstride + (long)o * a.Ipad;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int i = 4 * lane + 256 * j;
+          const f4 wv = i < a.I ? *reinterpret_cast<const f4*>(wr + i) : (f4)(0.f);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += xv[k][j][0] * wv[0] + xv[k][j][1] * wv[1] + xv[k][j][2] * wv[2] + xv[k][j][3] * wv[3];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (g[k] < 0) continue;
+        const float* wr = a.w + (long)g[k] * a.wstride + (long)o * a.Ipad;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int i = 4 * lane + 256 * j;
+          const f4 wv = i < a.I ? *reinterpret_cast<const f4*>(wr + i) : (f4)(0.f);
+          acc[k] += xv[k][j][0] * wv[0] + xv[k][j][1] * wv[1] + xv[k][j][2] * wv[2] + xv[k][j][3] * wv[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane < 4 && g[lane] >= 0) {                           // (rows outside every group stay untouched, as in conv.hip)
+      const long at = (long)(r0 + lane) * a.O + o;
+      float v = a.alpha * (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]);
+      if (a.res) v += a.beta * a.res[at];
+      a.y[at] = v;
+    }
+  }
+}
+
 static bool ml_fill(MLArgs& a, const void* x, const int* seg, const float* const* w, const int* O, int L, int R, int I, int Ipad, int ngroups) {
   if (!x || !w || !O || L < 1 || L > ML_MAXL || R < 0 || I < 1 || I > 512 || Ipad < I || ngroups < 1 || ngroups > HDMOE_MAX_GROUPS) return false;
   a.x = (const float*)x; a.seg = seg; a.L = L; a.R = R; a.I = I; a.Ipad = Ipad; a.ngroups = ngroups; a.c = 0.f;
@@ -134,6 +204,26 @@ static bool ml_fill(MLArgs& a, const void* x, const int* seg, const float* const
 }
 
 }  // namespace
+
+// Grouped fp32 linear with 256 <= I <= 1024 on one-position rows (H = W = 1): see glin_f32_kernel.  Same return convention as the other
+// *_try_launch helpers (1 = outside the domain).
+int glin_try_launch(const ConvArgs& c, int dtype, hipStream_t stream) {
+  static const bool off = getenv("HDMOE_GLIN") && atoi(getenv("HDMOE_GLIN")) == 0;
+  if (off || dtype != HDMOE_F32 || c.stride != 1 || c.ones || c.H != 1 || c.W != 1 || c.Ho != 1 || c.Wo != 1 || c.Cin != c.Cphys) return 1;
+  if (c.Cin < 256 || c.Cin > 1024 || c.Cin % 4 || c.Ipad % 4 || c.Cout != c.Cstore || c.N < 1) return 1;
+  for (int g = 0; g < c.ngroups; ++g) if (c.kh[g] != 1 || c.kw[g] != 1 || c.pt[g] || c.pl[g]) return 1;
+  if (((uintptr_t)c.x | (uintptr_t)c.w) & 15) return 1;
+  GLArgs a;
+  a.x = (const float*)c.x; a.w = (const float*)c.w; a.y = (float*)c.y; a.res = (const float*)c.res; a.seg = c.seg; a.wstride = c.wstride;
+  a.R = c.N; a.I = c.Cin; a.Ipad = c.Ipad; a.O = c.Cout; a.ngroups = c.ngroups; a.alpha = c.alpha; a.beta = c.beta;
+  const dim3 grid((unsigned)((c.N + 3) / 4));
+  const int nj = (c.Cin + 255) / 256;
+  if (nj == 1) hipLaunchKernelGGL(glin_f32_kernel<1>, grid, dim3(256), 0, stream, a);
+  else if (nj == 2) hipLaunchKernelGGL(glin_f32_kernel<2>, grid, dim3(256), 0, stream, a);
+  else if (nj == 3) hipLaunchKernelGGL(glin_f32_kernel<3>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(glin_f32_kernel<4>, grid, dim3(256), 0, stream, a);
+  return hdmoe_launch_status();
+}
 
 extern "C" {
 

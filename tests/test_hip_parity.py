@@ -682,6 +682,30 @@ def test_tiny_cout_weight_gradient(N, H, W, Cin, Cout, k):
     close_scaled(wd.grad, wr.grad, 5e-3, msg="dw")           # fp32 accumulation of exact bf16 products; the order differs
 
 
+@pytest.mark.parametrize("R,I,O,segs", [(512, 768, 128, [0, 130, 131, 400, 512]), (37, 768, 64, [0, 0, 30, 30, 33]), (9, 256, 48, None), (50, 1024, 32, [0, 50])])
+def test_grouped_fp32_linear_with_a_long_input(R, I, O, segs):
+    """The experts' text projection (`map_text`, 768 -> emb_size, fp32, one position per routed row): the dedicated kernel
+    (csrc/mlinear.hip glin) against torch -- segment boundaries inside a row quad, an empty expert, unrouted tail rows."""
+    from hdmoe_hip import ops
+    torch.manual_seed(R + O)
+    x = torch.randn(R, I)
+    G = 1 if segs is None else len(segs) - 1
+    ws = [torch.randn(O, I) / I ** 0.5 for _ in range(G)]
+    xd = x.to(DEV)
+    wd = [torch.nn.Parameter(w.to(DEV)) for w in ws]
+    if segs is None:
+        y = ops.mp_conv(xd, wd[0], 1.0, normalize=False)
+        ref = x @ ws[0].t()
+        close(y, ref, rtol=1e-4, atol=1e-4)
+        return
+    seg = torch.tensor(segs, dtype=torch.int32, device=DEV)
+    y = ops.mp_conv(xd, wd, 1.0, seg=seg, normalize=False)
+    for g in range(G):
+        a, b = segs[g], segs[g + 1]
+        if b > a:
+            close(y[a:b], x[a:b] @ ws[g].t(), rtol=1e-4, atol=1e-4)
+
+
 def test_dispatch_plan_matches_reference_order():
     """Expert-contiguous, sample-stable permutation == concatenation of the reference's x[mask] per expert."""
     from hdmoe_hip import ops
