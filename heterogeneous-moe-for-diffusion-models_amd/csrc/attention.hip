@@ -694,6 +694,200 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dkv_mfma_kernel(bf16* dk, bf1
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Merged backward: dq, dk, dv of a sample's heads from ONE evaluation of the probabilities.  The two kernels above each recompute
+// p = exp2(S') (16 v_exp_f32 per tile and wave: the instruction that bounds them).  Here a tile (32 queries x 32 keys) is evaluated once,
+// in the dk / dv kernel's orientation (rows = queries, columns = keys), whose accumulator layout puts the contraction index of the dQ
+// product -- the keys -- across the LANES: the packed bf16 dS tile takes a round trip through a wave-private 2-KB LDS tile (written in
+// the pack order the dK product already produced, XOR-swizzled 8-byte chunks, double-buffered so that the read-back of tile t - 1 runs
+// beside the exps of tile t) and returns through the transposing read as the B operand of  dQ^T[d][q] += K^T[d][k] dS^T[k][q];  K^T of
+// the pass's 32 keys is a constant fragment pair.
+// Who owns what: the four waves of a workgroup walk the key blocks TOGETHER (one 32-key block per pass) and split the QUERIES -- wave w
+// owns query tiles 8w .. 8w + 7 for every key block, so its dQ^T tiles accumulate in registers (8 x 4 VGPRs, the tile loop is unrolled)
+// and are stored once per head; dK / dV of a pass are the sum of the four waves' partial sums, which meet in LDS (two barriers per pass).
+// (A first version gave each wave its own key block and added the dQ^T tiles into an LDS accumulator: ds_add_f32 costs ~64 cycles per
+// wave instruction, 4 per tile -- 1.66 ms instead of 0.68 without the adds.)  delta is computed while the head's dO / out rows are staged.
+constexpr int MG_WAVES = 4, MG_TPW = ATT_HS / 32 / MG_WAVES;  // query tiles per wave
+constexpr int MG_IMG = 2 * ATT_IMG + ATT_HS * 16;            // Q | dO | shifts of one head
+constexpr int MG_RED = 2 * (MG_WAVES - 1) * 32 * 8 * 4;      // dK | dV partial sums of waves 1-3, two buffers
+constexpr int MG_LDS = MG_IMG + MG_RED + MG_WAVES * 4096 + MG_WAVES * 256 + ATT_CONST;
+DEVI void wave_lds_fence() {                                 // (same wave: the LDS keeps the order; this only stops the compiler)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DEVI bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+  return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_merged_kernel(bf16* dq, bf16* dk, bf16* dv, const bf16* dout, const bf16* out,
+                                                                const bf16* q, const bf16* k, const bf16* v, const float* lse, int Sq,
+                                                                int Skv, int H, int hpw, float scale, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+  unsigned char* imgQ = smem_attn;
+  unsigned char* imgD = imgQ + ATT_IMG;
+  unsigned char* imgS = imgD + ATT_IMG;
+  float* red = reinterpret_cast<float*>(smem_attn + MG_IMG);  // [2][3 waves][32 keys][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  unsigned char* dst = smem_attn + MG_IMG + MG_RED + wave * 4096;          // this wave's two dS^T tiles [32 keys][32 queries] bf16
+  unsigned char* kim = smem_attn + MG_IMG + MG_RED + MG_WAVES * 4096 + wave * 256;  // this wave's copy of the pass's K rows [32][8 B]
+  unsigned char* cb = smem_attn + MG_IMG + MG_RED + MG_WAVES * 4096 + MG_WAVES * 256;
+  const int b = blockIdx.y, E = H * 4;
+  const_block(cb, tid);
+  const int Sq32 = (Sq + 31) & ~31, ntq = Sq32 >> 5;
+  const int t0w = wave * MG_TPW;                              // this wave's query tiles [t0w, t0w + MG_TPW) (those below ntq)
+  // per-lane constants of the transposed path
+  const int p4 = lane & 3, qp = (lane & 15) >> 2, g16 = lane >> 4;
+  // write side: this lane = key column r, rows (queries) 8 i + 4 hh + 0..3 -> chunk 2 i + hh of row r, swizzled with (r & 7)
+  int woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) woff[i] = r * 64 + (((2 * i + hh) ^ (r & 7)) << 3);
+  // read side (B operand of slice s): rows k = 16 s + 8 hh + qp (+4), query chunk 4 (g16 & 1) + p4
+  int roff[2][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * s2 + 8 * hh + qp + 4 * j, chunk = 4 * (g16 & 1) + p4;
+      roff[s2][j] = row * 64 + ((chunk ^ (row & 7)) << 3);
+    }
+  // A-fragment pointers of this wave's FIRST tile (lanes hh == 0: the Q / dO row; lanes hh == 1: the query's shift row)
+  const unsigned char* bQ0 = (hh == 0 ? imgQ + r * 8 : imgS + r * 16) + t0w * (hh == 0 ? 256 : 512);
+  const unsigned char* bQ1 = (hh == 0 ? imgQ + r * 8 : imgS + r * 16 + 8) + t0w * (hh == 0 ? 256 : 512);
+  const unsigned char* bD0 = (hh == 0 ? imgD + r * 8 : imgS + r * 16) + t0w * (hh == 0 ? 256 : 512);
+  const unsigned char* bD1 = hh == 0 ? cb + CB_ZERO : imgS + r * 16 + 8 + t0w * 512;
+  const unsigned char* bQt = tr_ptr(imgQ, cb, lane, false) + (p4 == 0 ? t0w * 256 : 0);
+  const unsigned char* bDt = tr_ptr(imgD, cb, lane, false) + (p4 == 0 ? t0w * 256 : 0);
+  const int astep = hh == 0 ? 256 : 512, d1step = hh == 0 ? 0 : 512, tstep = p4 == 0 ? 256 : 0;
+  int parity = 0;
+  for (int hi = 0; hi < hpw; ++hi) {
+    const int h = blockIdx.x * hpw + hi;
+    if (h >= H) break;                                        // (uniform)
+    __syncthreads();                                          // the previous head's sweeps are done
+    for (int rr = tid; rr < Sq32; rr += 256) {
+      uint2 wq = make_uint2(0, 0), wd = make_uint2(0, 0);
+      float ls = 1.0e4f, dl = 0.f;                            // queries past Sq: p = exp2(-1e4) = 0
+      if (rr < Sq) {
+        const long ro = ((long)b * Sq + rr) * E + h * 4;
+        wq = *reinterpret_cast<const uint2*>(q + ro);
+        wd = *reinterpret_cast<const uint2*>(dout + ro);
+        const bf16x4 a = __builtin_bit_cast(bf16x4, wd), o4 = *reinterpret_cast<const bf16x4*>(out + ro);
+        dl = (float)a[0] * (float)o4[0] + (float)a[1] * (float)o4[1] + (float)a[2] * (float)o4[2] + (float)a[3] * (float)o4[3];
+        ls = lse[((long)b * H + h) * Sq + rr] * 1.4426950408889634f;
+      }
+      *reinterpret_cast<uint2*>(imgQ + rr * 8) = wq;
+      *reinterpret_cast<uint2*>(imgD + rr * 8) = wd;
+      const bf16x8 sa = shift_frag(-ls, 0);
+      bf16x8 w = shift_frag(-dl, 4);
+      w[0] = sa[0]; w[1] = sa[1];
+      *reinterpret_cast<bf16x8*>(imgS + rr * 16) = w;
+    }
+    __syncthreads();
+    float dqa[MG_TPW][4];
+#pragma unroll
+    for (int j = 0; j < MG_TPW; ++j) { dqa[j][0] = 0.f; dqa[j][1] = 0.f; dqa[j][2] = 0.f; dqa[j][3] = 0.f; }
+    for (int k0 = 0; k0 < Skv; k0 += 32) {                    // passes: one 32-key block, all four waves
+      const bool kok = k0 + r < Skv;
+      const long krow = ((long)b * Skv + k0 + (kok ? r : 0)) * E + h * 4;
+      const bf16x8 fkB = hh == 0 ? scaled_frag(k + krow, kok, c) : ones_frag(0, 2);
+      const bf16x8 fvB = hh == 0 ? head_frag(v + krow, kok) : ones_frag(4, 3);
+      // K^T of the pass's keys in the NATURAL slot order k = 16 s + 8 hh + j (the order the transposed dS^T comes back in)
+      wave_lds_fence();
+      if (hh == 0) *reinterpret_cast<uint2*>(kim + r * 8) = kok ? *reinterpret_cast<const uint2*>(k + krow) : make_uint2(0, 0);
+      wave_lds_fence();
+      bf16x8 kt[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned char* pa = p4 == 0 ? kim + (16 * s2 + 8 * hh + qp) * 8 : cb + CB_ZERO;
+        const unsigned char* pb = p4 == 0 ? kim + (16 * s2 + 8 * hh + qp + 4) * 8 : cb + CB_ZERO;
+        kt[s2] = tr_pair(pa, pb);
+      }
+      f32x16 ak = (f32x16)(0.f), av = (f32x16)(0.f);
+      // the transposed half of tile j - 1 runs inside iteration j, beside that tile's exps (its LDS round trip is long over by then)
+      auto dq_part = [&](const int jp) {
+        const unsigned char* src = dst + (jp & 1) * 2048;
+        const bf16x8 b0 = tr_pair(src + roff[0][0], src + roff[0][1]);
+        const bf16x8 b1 = tr_pair(src + roff[1][0], src + roff[1][1]);
+        f32x16 dqt = mfma_bf16(kt[0], b0, (f32x16)(0.f));     // dQ^T[d][q] of that tile and this key block
+        dqt = mfma_bf16(kt[1], b1, dqt);
+        dqa[jp][0] += dqt[0]; dqa[jp][1] += dqt[1]; dqa[jp][2] += dqt[2]; dqa[jp][3] += dqt[3];
+      };
+#pragma unroll
+      for (int j = 0; j < MG_TPW; ++j) {
+        if (t0w + j < ntq) {                                  // (uniform over the wave)
+          wave_lds_fence();                                   // iteration j - 1 wrote buffer (j - 1) & 1 and read buffer j & 1
+          const bf16x8 fqr = frag2(bQ0 + j * astep, bQ1 + j * astep);
+          const bf16x8 fdr = frag2(bD0 + j * astep, bD1 + j * d1step);
+          const bf16x8 fd0 = tr_frag(bDt + j * tstep), fd1 = tr_frag(bDt + j * tstep + 128);
+          const bf16x8 fq0 = tr_frag(bQt + j * tstep), fq1 = tr_frag(bQt + j * tstep + 128);
+          f32x16 s = mfma_bf16(fqr, fkB, (f32x16)(0.f));      // S'[q][k] = c q.k - lse[q]: rows = queries, columns = keys
+          f32x16 dp = mfma_bf16(fdr, fvB, (f32x16)(0.f));     // dP'[q][k] = dO[q] . V[k] - delta[q]
+          if (j > 0) dq_part(j - 1);
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            s[reg] = __builtin_amdgcn_exp2f(s[reg]);
+            dp[reg] *= s[reg];
+          }
+          const bf16x8 ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);
+          av = mfma_bf16(fd0, pack8(s, 0), av);               // dV^T[d][k] += dO^T[d][q] P[q][k]
+          av = mfma_bf16(fd1, pack8(s, 1), av);
+          ak = mfma_bf16(fq0, ds0, ak);                       // dK^T[d][k] += Q^T[d][q] dS[q][k]
+          ak = mfma_bf16(fq1, ds1, ak);
+          const u32x4 w0 = __builtin_bit_cast(u32x4, ds0), w1 = __builtin_bit_cast(u32x4, ds1);
+          unsigned char* dw = dst + (j & 1) * 2048;           // dS -> LDS (key-major), read back transposed in the next iteration
+          *reinterpret_cast<u32x2*>(dw + woff[0]) = (u32x2){w0.x, w0.y};
+          *reinterpret_cast<u32x2*>(dw + woff[1]) = (u32x2){w0.z, w0.w};
+          *reinterpret_cast<u32x2*>(dw + woff[2]) = (u32x2){w1.x, w1.y};
+          *reinterpret_cast<u32x2*>(dw + woff[3]) = (u32x2){w1.z, w1.w};
+        }
+      }
+      wave_lds_fence();
+      {
+        const int nj = min(MG_TPW, ntq - t0w);                // tiles this wave had (<= 0: none)
+#pragma unroll
+        for (int j = 0; j < MG_TPW; ++j) if (j == nj - 1) dq_part(j);
+      }
+      // dK / dV of the pass: the four waves' partial sums meet in LDS (buffer `parity`: the previous pass's may still be read)
+      float* mine = red + ((long)(parity * (MG_WAVES - 1) + wave - 1) * 32 + r) * 8;
+      if (wave > 0 && hh == 0) {
+        *reinterpret_cast<f32x4*>(mine) = (f32x4){ak[0], ak[1], ak[2], ak[3]};
+        *reinterpret_cast<f32x4*>(mine + 4) = (f32x4){av[0], av[1], av[2], av[3]};
+      }
+      __syncthreads();
+      if (wave == 0 && hh == 0 && kok) {
+#pragma unroll
+        for (int w2 = 0; w2 < MG_WAVES - 1; ++w2) {
+          const float* o2 = red + ((long)(parity * (MG_WAVES - 1) + w2) * 32 + r) * 8;
+          const f32x4 pk = *reinterpret_cast<const f32x4*>(o2), pv = *reinterpret_cast<const f32x4*>(o2 + 4);
+          ak[0] += pk[0]; ak[1] += pk[1]; ak[2] += pk[2]; ak[3] += pk[3];
+          av[0] += pv[0]; av[1] += pv[1]; av[2] += pv[2]; av[3] += pv[3];
+        }
+        bf16x4 ok4, ov4;
+        ok4[0] = (bf16)(ak[0] * scale); ok4[1] = (bf16)(ak[1] * scale); ok4[2] = (bf16)(ak[2] * scale); ok4[3] = (bf16)(ak[3] * scale);
+        ov4[0] = (bf16)av[0]; ov4[1] = (bf16)av[1]; ov4[2] = (bf16)av[2]; ov4[3] = (bf16)av[3];
+        *reinterpret_cast<bf16x4*>(dk + krow) = ok4;
+        *reinterpret_cast<bf16x4*>(dv + krow) = ov4;
+      }
+      parity ^= 1;                                            // (one barrier per pass: the other buffer is free again two passes later)
+    }
+    // dq of this wave's query tiles, straight from the registers
+#pragma unroll
+    for (int j = 0; j < MG_TPW; ++j) {
+      const int qq = (t0w + j) * 32 + r;
+      if (hh == 0 && qq < Sq) {
+        bf16x4 o4;
+        o4[0] = (bf16)(dqa[j][0] * scale); o4[1] = (bf16)(dqa[j][1] * scale); o4[2] = (bf16)(dqa[j][2] * scale); o4[3] = (bf16)(dqa[j][3] * scale);
+        *reinterpret_cast<bf16x4*>(dq + ((long)b * Sq + qq) * E + h * 4) = o4;
+      }
+    }
+  }
+}
+
 static inline bool attn_mfma_ok(int H, const void* a, const void* b2, const void* c2, const void* d2) {
   static const bool off = getenv("HDMOE_ATTN_VALU") != nullptr;
   return !off && H >= 1 && H <= 4096 && (((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 7) == 0;
@@ -738,6 +932,16 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
   if constexpr (sizeof(T) == 2 && D == 4) {
     if (!bias && attn_mfma_ok(H, dq, dk, dv, dout) && attn_mfma_ok(H, out, q, k, v)) {
       const float c = scale * 1.4426950408889634f;
+      static const bool merged = !(getenv("HDMOE_ATTN_BWD_MERGED") && atoi(getenv("HDMOE_ATTN_BWD_MERGED")) == 0);
+      if (merged && Sq <= ATT_HS) {                           // one evaluation of the probabilities for dq, dk and dv
+        static bool attr = false;
+        if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)attn_bwd_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS); }
+        int hg = (int)cdiv(512, B); if (hg > H) hg = H; if (hg < 1) hg = 1;
+        const int hpw = (int)cdiv(H, hg);
+        hipLaunchKernelGGL(attn_bwd_merged_kernel, dim3(cdiv(H, hpw), B), dim3(64 * MG_WAVES), MG_LDS, st, (bf16*)dq, (bf16*)dk, (bf16*)dv,
+                           (const bf16*)dout, (const bf16*)out, (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, Sq, Skv, H, hpw, scale, c);
+        return hdmoe_launch_status();
+      }
       const size_t lds_q = 4 * ATT_IMG + ATT_CONST, lds_kv = 2 * ATT_KV_BUF + ATT_CONST + 8 * 32 * 8 * 4;
       const int nb32 = (int)cdiv(Skv, 32), nkb = nb32 >= 5 ? 8 : (nb32 >= 3 ? 4 : nb32);
       attn_mfma_attrs();
