@@ -143,7 +143,7 @@ def roofline_leg(step_fn, n_steps):
             a["flops"] += conv_flops(info) * info.get("mult", 1.0)     # fused launches: dgrad + wgrad (x 2), conv_res1 + conv_res2 (I = Cin + C)
             a["n"] += 1
     # v_exp_f32 issues at 8 cycles per wave-instruction (MI355X_MICROARCH.md): 1024 SIMDs x 64 lanes / 8 cycles x 2.4 GHz exps per second.
-    # The forward evaluates one exp per (query, key, head) pair; the backward recomputes the probabilities in both of its kernels (dq; dk + dv).
+    # The forward evaluates one exp per (query, key, head) pair; so does the merged backward kernel (the two-kernel form, > 1024 queries, two).
     # (measured on these kernels with SQ_ACTIVE_INST_VALU at a 2.08 GHz clock: ~16 VALU-active cycles per v_exp_f32 wave instruction --
     #  against THAT rate the forward is at ~75 %, the backward kernels at 80-90 % of their instruction-issue floors)
     exp_peak = 1024 * 64 / 8 * 2.4e9
@@ -152,7 +152,8 @@ def roofline_leg(step_fn, n_steps):
         i = t["info"]
         ms = sorted(t["ms"])[len(t["ms"]) // 2]
         pairs = float(i["B"]) * i["H"] * i["Sq"] * i["Skv"]
-        exps = pairs * (1 if i["dir"] == "fwd" else 2)
+        merged = i["Sq"] <= 1024 and os.environ.get("HDMOE_ATTN_BWD_MERGED", "1") != "0"       # one evaluation for dq, dk and dv (csrc/attention.hip)
+        exps = pairs * (1 if (i["dir"] == "fwd" or merged) else 2)
         E = i["H"] * i["D"]
         hbm = i["B"] * E * i["esz"] * ((2 * i["Sq"] + 2 * i["Skv"]) if i["dir"] == "fwd" else (5 * i["Sq"] + 4 * i["Skv"]))
         rep.append(dict(shape=key, median_ms=round(ms, 4), launches_per_step=len(t["ms"]) / n_steps, exps_per_s=round(exps / (ms * 1e-3), 1),
