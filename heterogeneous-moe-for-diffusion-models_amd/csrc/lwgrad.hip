@@ -377,7 +377,12 @@ int towg_try_launch(const void* x, const void* dy, float* G, int N, int H, int W
   if (!x || !dy || !G || ((uintptr_t)x & 3)) return 1;
   TowgArgs a;
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.G = G; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = (k - 1) / 2;
+  if (k == 1) {                                              // pointwise: no halo, the image shape is irrelevant (ops flattens such tensors
+    const long total = (long)N * H * W;                       // to ONE row of N * H * W pixels): re-tile as rows of 256 pixels
+    if (total % 256 == 0 && total / 256 < (1l << 30)) { a.N = 1; a.H = (int)(total / 256); a.W = 256; N = 1; H = a.H; W = 256; }
+  }
   a.TH = H < 8 ? H : 8;
+  if (k == 1 && H >= 4 && (long)N * ((H + 7) / 8) < 256) a.TH = 4;   // (enough tiles for every CU)
   while (a.TH > 1 && (size_t)(a.TH + k - 1) * (W + k - 1) * 16 > 48 * 1024) a.TH >>= 1;
   if ((size_t)(a.TH + k - 1) * (W + k - 1) * 16 > 48 * 1024) return 1;
   a.tiles_y = (H + a.TH - 1) / a.TH;
