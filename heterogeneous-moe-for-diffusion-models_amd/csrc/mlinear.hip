@@ -132,9 +132,16 @@ __global__ __launch_bounds__(256) void mlin_wgrad_kernel(MLArgs a) {
 // dot products meet by cross-lane adds.
 struct GLArgs { const float* x; const float* w; float* y; const float* res; const int* seg; long wstride; int R, I, Ipad, O, ngroups; float alpha, beta; };
 
+typedef __attribute__((ext_vector_type(4))) float glf4;
+// (ONE fixed fma order for both code paths below: a row's result must not depend on whether its quad straddles a segment boundary --
+//  the batch-independence test compares a sample's output bit for bit across batch compositions)
+DEVI float gl_dot4(float acc, const glf4 x, const glf4 w) {
+  return __builtin_fmaf(x[3], w[3], __builtin_fmaf(x[2], w[2], __builtin_fmaf(x[1], w[1], __builtin_fmaf(x[0], w[0], acc))));
+}
+
 template <int NJ>                                             // NJ = ceil(I / 256) float4 pieces per lane and row
 __global__ __launch_bounds__(256) void glin_f32_kernel(GLArgs a) {
-  typedef __attribute__((ext_vector_type(4))) float f4;
+  typedef glf4 f4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * 4;
   int g[4];
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void glin_f32_kernel(GLArgs a) {
           const int i = 4 * lane + 256 * j;
           const f4 wv = i < a.I ? *reinterpret_cast<const f4*>(wr + i) : (f4)(0.f);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += xv[k][j][0] * wv[0] + xv[k][j][1] * wv[1] + xv[k][j][2] * wv[2] + xv[k][j][3] * wv[3];
+          for (int k = 0; k < 4; ++k) acc[k] = gl_dot4(acc[k], xv[k][j], wv);
         }
       }
     } else {
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void glin_f32_kernel(GLArgs a) {
         for (int j = 0; j < NJ; ++j) {
           const int i = 4 * lane + 256 * j;
           const f4 wv = i < a.I ? *reinterpret_cast<const f4*>(wr + i) : (f4)(0.f);
-          acc[k] += xv[k][j][0] * wv[0] + xv[k][j][1] * wv[1] + xv[k][j][2] * wv[2] + xv[k][j][3] * wv[3];
+          acc[k] = gl_dot4(acc[k], xv[k][j], wv);
         }
       }
     }
