@@ -706,6 +706,20 @@ def test_grouped_fp32_linear_with_a_long_input(R, I, O, segs):
             close(y[a:b], x[a:b] @ ws[g].t(), rtol=1e-4, atol=1e-4)
 
 
+def test_two_kernel_attention_backward_still_matches():
+    """The merged backward kernel is the default for up to 1024 queries; the dq + dk/dv pair it replaced stays in the library for longer
+    sequences and as an A/B switch (HDMOE_ATTN_BWD_MERGED=0, read once per process): exercised here in a child process through the same
+    check tools/attn_bench.py runs (fp64 softmax on the bf16 operands, forward + three gradients, five shapes incl. 77 keys)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HDMOE_ATTN_BWD_MERGED="0")
+    code = ("import sys; sys.argv = ['attn_bench.py']; sys.path.insert(0, %r); import attn_bench as a; import hdmoe_hip; hdmoe_hip.lib();"
+            "ok = a.check(2, 1024, 1024, 8) and a.check(3, 300, 77, 8) and a.check(2, 96, 40, 3) and a.check(1, 33, 20, 8);"
+            "sys.exit(0 if ok else 1)") % os.path.join(root, "tools")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_dispatch_plan_matches_reference_order():
     """Expert-contiguous, sample-stable permutation == concatenation of the reference's x[mask] per expert."""
     from hdmoe_hip import ops

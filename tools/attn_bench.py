@@ -85,7 +85,9 @@ def timeit(B, Sq, Skv, H, iters=10):
         s.record(); gr.replay(); e.record(); torch.cuda.synchronize()
         res.append(1e3 * s.elapsed_time(e) / iters)
     exps = B * H * Sq * Skv
-    print(f"time B={B} Sq={Sq} Skv={Skv} H={H}: fwd {res[0]:7.1f} us ({exps / res[0] / 1e6:5.2f} Texp/s)   bwd (dq + dkv) {res[1]:7.1f} us ({2 * exps / res[1] / 1e6:5.2f} Texp/s)", flush=True)
+    merged = Sq <= 1024 and os.environ.get("HDMOE_ATTN_BWD_MERGED", "1") != "0"        # one evaluation of the probabilities instead of two
+    print(f"time B={B} Sq={Sq} Skv={Skv} H={H}: fwd {res[0]:7.1f} us ({exps / res[0] / 1e6:5.2f} Texp/s)   bwd ({'merged' if merged else 'dq + dk/dv'}) {res[1]:7.1f} us "
+          f"({(1 if merged else 2) * exps / res[1] / 1e6:5.2f} Texp/s)", flush=True)
 
 
 if __name__ == "__main__":
