@@ -122,13 +122,21 @@ __global__ __launch_bounds__(256) void lwg_bf16_kernel(LwgArgs a) {
   for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int u = 0; u < IT; ++u) acc[t][u] = (f32x16)(0.f);
+  // the sub-tiles are WAVE-PRIVATE: the LDS keeps one wave's writes and reads in order, so a slice hand-over needs a compiler fence, not a
+  // workgroup barrier (two per slice marched the four waves in lockstep until round 3); the one barrier is in front of the shared flush
+  auto wfence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   const long iters = (u1 - u0 + 3) >> 2;
   if (u0 + wave < u1) load(u0 + wave);
   for (long it = 0; it < iters; ++it) {
     const long u = u0 + wave + 4 * it;
     const bool valid = u < u1;
+    wfence();
     if (valid) store();
-    __syncthreads();
+    wfence();
     if (u + 4 < u1) load(u + 4);
     if (valid) {
 #pragma unroll
@@ -144,8 +152,8 @@ __global__ __launch_bounds__(256) void lwg_bf16_kernel(LwgArgs a) {
           for (int v = 0; v < IT; ++v) acc[t][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy[t], fx[v], acc[t][v], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();                                            // every wave is done with its sub-tiles: the flush re-uses the whole buffer
   lwg_flush<OT, IT>(acc, reinterpret_cast<float*>(lds), a.G[g], o0, i0, a.I, tid);
 }
 
