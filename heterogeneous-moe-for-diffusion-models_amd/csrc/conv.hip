@@ -1248,6 +1248,10 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
     return rc == 1 ? HDMOE_EINVAL : rc;
   }
   if (dtype != HDMOE_F32 && dtype != HDMOE_BF16) return HDMOE_EDTYPE;
+  {                                                        // k x k expert layers on 32 x 32 maps: whole-image streaming kernel (conv7.hip)
+    const int rc = conv7_try_launch(a, dtype, stream);
+    if (rc <= 0) return rc;
+  }
   {                                                        // k x k layers of the experts / trunks: persistent LDS-DMA kernel (conv6.hip)
     const int rc = conv6_try_launch(a, nullptr, dtype, stream);
     if (rc <= 0) return rc;

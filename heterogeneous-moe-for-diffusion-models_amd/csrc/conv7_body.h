@@ -1,0 +1,275 @@
+// Device body of the conv7 kernel: whole-image streaming implicit-GEMM convolution for the k x k expert layers on 32 x 32 maps
+// (forward and dgrad of MP_Conv, reference models/model_internals.py:253-275, grouped by expert as in models/model_config1.py:25-37).
+//
+// Why a third kernel next to conv6 ("Round 4"): on this model's 32 / 64-channel layers conv6's 256-pixel work
+// units spend two thirds of their time outside the matrix pipe -- 1.5 LDS fragment reads per MFMA with the address arithmetic of a
+// run-time tap cursor, a unit decode and a halo plan per unit, a barrier per stage of a 512-pixel tile.  Here
+//   * a work unit is a WHOLE image: one 8-wave workgroup per CU keeps the image's current 32-channel chunk (32 rows x 35 pixel slots x
+//     64 B, pad slots shared between neighbouring rows and zeroed once) in LDS, double-buffered, filled by LDS-DMA with one scalar
+//     offset per 1-KB piece (no per-unit halo plan: the tile IS the image); units are dealt to the workgroups in a snake over the
+//     cost-sorted image list, so a workgroup with a 5x5 image also gets a 3x3 one;
+//   * wave w owns output rows 4w .. 4w+3 (four 32-pixel blocks) and all output channels: a weight fragment is reused by four (eight
+//     with 64 output channels) MFMAs and an input-row fragment by every kernel row of a stage that touches it --
+//     0.56 - 0.69 ds_read_b128 per MFMA instead of 1.0 - 1.5;
+//   * the tap schedule (kernel column outer, kernel rows in stages of <= 4 / CO taps) is a compile-time table per kernel size: every
+//     LDS address is a per-lane constant (one of seven column shifts) plus a scalar, rows outside the image read a zero row;
+//   * weights stream through a 2 x 8 KB ring, one 1-KB DMA piece per wave and stage, counted vmcnt waits keep the next image's tile
+//     and the epilogue stores in flight across the stage barriers.
+#pragma once
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* c7_lptr_t;
+
+struct C7Args {
+  const void* x; const void* w; void* y; const void* res; const int* seg;
+  long wstride;                        // elements per group in the weight image [g][tap][Cout][Cin]
+  int N, Cin, Cout, ngroups;           // H = W = 32
+  int ks[HDMOE_MAX_GROUPS], order[HDMOE_MAX_GROUPS];   // kernel size per group; groups in descending kernel size
+  float alpha, beta;
+  int xbytes, wbytes;
+  int dbg;                             // development ablations: 1 skip the MFMAs, 2 skip the tile DMA of later units, 4 skip the stores
+};
+
+constexpr int C7_PITCH = 35;                                   // pixel slots per image row: 32 + 3 shared pad slots
+constexpr int C7_ROWB = C7_PITCH * 64;                         // bytes per row of a tile
+constexpr int C7_TILE = (32 * C7_PITCH + 3) * 64;              // 71,872 B: 32 rows + the pad behind the last one
+constexpr int C7_WBUF = 8192;                                  // one weight stage: 4 taps x 32 rows or 2 taps x 64 rows, 64 B each
+constexpr int C7_T0 = 2 * C7_WBUF;                             // tiles start behind the weight ring (keeps every row address >= 0)
+constexpr int C7_ZROW = C7_T0 + 2 * C7_TILE;                   // 38 zero pixel slots: what a row outside the image reads
+constexpr int C7_LDS = C7_ZROW + 38 * 64;                      // 162,560 B
+
+// One stage = up to T consecutive kernel rows of one kernel column.
+template <int KS, int CO> struct C7Sched {
+  static constexpr int T = 4 / CO;
+  static constexpr int SPC = (KS + T - 1) / T;                 // stages per kernel column
+  static constexpr int NS = KS * SPC;                          // stages per channel chunk
+  // taps of stage i of a column, balanced (5 -> 3 + 2, 7 -> 4 + 3 / 2 + 2 + 2 + 1)
+  static constexpr int ky0(int i) { return (KS * i) / SPC; }
+  static constexpr int nt(int i) { return (KS * (i + 1)) / SPC - (KS * i) / SPC; }
+};
+
+struct C7Unit { int g, n, ks; };
+
+#define C7_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int CO, int KMASK>
+DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
+  const int CI = a.Cin >> 5;
+  const int cin2 = a.Cin * 2;
+
+  // ---- unit list: images of the groups in descending kernel size, dealt in a snake over the workgroups
+  int cum[HDMOE_MAX_GROUPS + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) {
+    int cnt = 0;
+    if (i < a.ngroups) { const int g = a.order[i]; cnt = a.seg ? a.seg[g + 1] - a.seg[g] : a.N; }
+    cum[i + 1] = cum[i] + cnt;
+  }
+  const int total = cum[HDMOE_MAX_GROUPS];
+  auto unit_at = [&](int q, C7Unit& u) -> bool {
+    const int pos = q * G + ((q & 1) ? G - 1 - bid : bid);
+    if (pos >= total) return false;
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < HDMOE_MAX_GROUPS; ++i) slot += (i < a.ngroups && pos >= cum[i]) ? 1 : 0;
+    int base = 0, g = 0;
+#pragma unroll
+    for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == slot) { base = cum[i]; g = a.order[i]; }
+    int ks = 3;
+#pragma unroll
+    for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == g) ks = a.ks[i];
+    u.g = g; u.ks = ks; u.n = (a.seg ? a.seg[g] : 0) + pos - base;
+    return true;
+  };
+
+  // ---- zero the pad slots of both tiles and the zero row (never written again: the DMA only touches data slots)
+  for (int i = tid; i < 33 * 12; i += 512) {
+    const int off = (i / 12) * C7_ROWB + (i % 12) * 16;
+    *reinterpret_cast<uint4*>(lds + C7_T0 + off) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(lds + C7_T0 + C7_TILE + off) = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = tid; i < 38 * 4; i += 512) *reinterpret_cast<uint4*>(lds + C7_ZROW + i * 16) = make_uint4(0, 0, 0, 0);
+
+  // ---- per-lane constants
+  // tile DMA: lane i of a piece holds pixel i >> 2 (of 16), LDS slot i & 3; it fetches the source slot (i & 3) ^ key(position)
+  const int dpx = lane >> 2;
+  const unsigned xlane = (unsigned)(dpx * cin2 + (((lane & 3) ^ (((3 + dpx) >> 2) & 3)) << 4));
+  // weight DMA: lane i holds output row i >> 2 (of 16), slot i & 3
+  const unsigned wlane = (unsigned)(dpx * cin2 + (((lane & 3) ^ ((dpx >> 2) & 3)) << 4));
+  // fragment reads: pixel column r + cc (cc = kernel column + 3 - pad, 0 .. 6), 16-channel k-step 0; k-step 1 = ^ 32
+  int acol[7];
+#pragma unroll
+  for (int cc = 0; cc < 7; ++cc) { const int col = r + cc; acol[cc] = (col << 6) + ((h ^ ((col >> 2) & 3)) << 4); }
+  const int wl = (r << 6) + ((h ^ ((r >> 2) & 3)) << 4);        // weight fragment of output row r, k-step 0
+
+  // issue this wave's 8 pieces (rows 4 wave .. 4 wave + 3, two halves each) of chunk c of image n into tile buffer tb
+  auto issue_tile = [&](int n, int c, int tb) {
+    const int lbase = C7_T0 + tb * C7_TILE + 3 * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = 4 * wave + (k >> 1), half = k & 1;
+      const int so = ((n * 32 + row) * 32 + half * 16) * cin2 + c * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c7_lptr_t)(lds + lbase + row * C7_ROWB + half * 1024), 16, xlane, so, 0, 0);
+    }
+  };
+  // this wave's piece of the weight stage (kernel column kx, rows ky0 .. ky0 + nt) of chunk c, group g, kernel size ks -> ring buffer sp
+  auto issue_wstage = [&](int g, int ks, int c, int kx, int ky0, int nt, int sp) {
+    const int ts = wave / (2 * CO), pc = wave % (2 * CO);       // tap slot, 16-row piece inside the tap
+    if (ts < nt) {
+      const int tap = (ky0 + ts) * ks + kx;
+      const int so = (int)(((long)g * a.wstride + (long)(tap * a.Cout + pc * 16) * a.Cin) * 2) + c * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c7_lptr_t)(lds + sp * C7_WBUF + wave * 1024), 16, wlane, so, 0, 0);
+    }
+  };
+
+  C7Unit cur, nxt;
+  int q = 0;
+  if (!unit_at(q, cur)) return;
+  bool has_next = unit_at(q + 1, nxt);
+  int tp = 0, sp = 0;                                           // tile / weight ring parity
+  auto nt0_of = [](int ks) { return ks == 3 ? C7Sched<3, CO>::nt(0) : (ks == 5 ? C7Sched<5, CO>::nt(0) : C7Sched<7, CO>::nt(0)); };
+  issue_wstage(cur.g, cur.ks, 0, 0, 0, nt0_of(cur.ks), 0);       // first stage of the unit's schedule: column 0, rows 0 .. nt0
+  issue_tile(cur.n, 0, 0);
+  bool first = true;
+
+  // ---- one image: all chunks, all stages; prefetches the next image's first tile and first weight stage
+  auto run_unit = [&](auto ks_tag) {
+    constexpr int KS = decltype(ks_tag)::value;
+    using S = C7Sched<KS, CO>;
+    constexpr int P = (KS - 1) / 2, Q = 3 - P;
+    f32x16 acc[4][CO];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int b = 0; b < CO; ++b) acc[m][b] = (f32x16)(0.f);
+
+    for (int c = 0; c < CI; ++c) {
+      const bool last_chunk = c == CI - 1;
+      const bool tile_next = (!last_chunk || has_next) && !((a.dbg & 2) && last_chunk);   // a tile is fetched beside this chunk's first stage
+      const int tbase = C7_T0 + tp * C7_TILE;
+#pragma unroll
+      for (int s = 0; s < S::NS; ++s) {
+        const int kx = s / S::SPC, si = s % S::SPC;             // (compile-time after unrolling)
+        const int ky0 = S::ky0(si), nt = S::nt(si);
+        // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free
+        if (s == 0) {
+          // older than everything needed here: nothing but (first chunk of a later unit) the previous unit's 8 * CO epilogue stores
+          if (c == 0 && !first) { if (CO == 2) C7_WAIT_BARRIER(16); else C7_WAIT_BARRIER(8); }
+          else C7_WAIT_BARRIER(0);
+        } else if (s == 1 && tile_next) {
+          C7_WAIT_BARRIER(8);                                   // the 8 tile pieces issued behind this stage's weight piece stay in flight
+        } else {
+          C7_WAIT_BARRIER(0);
+        }
+        // ---- next stage's weights, next tile
+        if (s + 1 < S::NS) {
+          const int s1 = s + 1;
+          issue_wstage(cur.g, KS, c, s1 / S::SPC, S::ky0(s1 % S::SPC), S::nt(s1 % S::SPC), sp ^ 1);
+        } else if (!last_chunk) {
+          issue_wstage(cur.g, KS, c + 1, 0, S::ky0(0), S::nt(0), sp ^ 1);
+        } else if (has_next) {
+          issue_wstage(nxt.g, nxt.ks, 0, 0, 0, nt0_of(nxt.ks), sp ^ 1);
+        }
+        if (s == 0 && tile_next) {
+          if (!last_chunk) issue_tile(cur.n, c + 1, tp ^ 1); else issue_tile(nxt.n, 0, tp ^ 1);
+        }
+        // ---- MFMAs of the stage: per 16-channel k-step, the nt + 3 input rows it touches, then per kernel row its weight fragment(s)
+        if (!(a.dbg & 1)) {
+          const int wb = sp * C7_WBUF;
+          const int row0 = 4 * wave - P + ky0;                  // image row of fragment j = 0
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            bf16x8 xf[7];
+#pragma unroll
+            for (int j = 0; j < nt + 3; ++j) {
+              const int row = row0 + j;
+              const int sb = ((unsigned)row < 32u) ? tbase + row * C7_ROWB : C7_ZROW;      // wave-uniform
+              xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((acol[kx + Q] ^ (k2 << 5)) + sb));
+            }
+#pragma unroll
+            for (int i = 0; i < nt; ++i) {
+              bf16x8 wf[CO];
+#pragma unroll
+              for (int b = 0; b < CO; ++b)
+                wf[b] = *reinterpret_cast<const bf16x8*>(lds + wb + (i * CO + b) * 2048 + (wl ^ (k2 << 5)));
+#pragma unroll
+              for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int b = 0; b < CO; ++b)
+                  acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b], xf[m + i], acc[m][b], 0, 0, 0);
+            }
+          }
+        }
+        sp ^= 1;
+      }
+      tp ^= 1;
+    }
+    // ---- epilogue: y = alpha * acc + beta * res, 16-byte stores (register quads paired across the half-waves)
+    if (!(a.dbg & 4)) {
+      bf16* Y = (bf16*)a.y;
+      const bf16* R = (const bf16*)a.res;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const long pix = (((long)cur.n * 32 + 4 * wave + m) * 32 + r) * a.Cout;
+#pragma unroll
+        for (int b = 0; b < CO; ++b)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = a.alpha * acc[m][b][8 * p + e];
+            if (R) {
+              const long o0 = pix + 32 * b + 16 * p + 4 * h;
+              const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);
+              const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] += a.beta * (float)r0[e]; v[4 + e] += a.beta * (float)r1[e]; }
+            }
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const unsigned A0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[0], (bf16)v[1]}), A1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[2], (bf16)v[3]});
+            const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
+            *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int b = 0; b < CO; ++b) asm volatile("" :: "v"(acc[m][b]));
+    }
+  };
+
+  while (true) {
+    if ((KMASK & 4) && cur.ks == 7) run_unit(std::integral_constant<int, 7>{});
+    else if ((KMASK & 2) && cur.ks == 5) run_unit(std::integral_constant<int, 5>{});
+    else run_unit(std::integral_constant<int, 3>{});
+    first = false;
+    if (!has_next) break;
+    cur = nxt;
+    ++q;
+    has_next = unit_at(q + 1, nxt);
+  }
+#endif
+}
+
+}  // namespace
+
+struct ConvArgs;
+struct C7Plan { C7Args a; unsigned G; int CO, kmask; };
+// Launch geometry of conv7 for one layer (conv7.hip; shared with the fused backward launch).  0 = planned, 1 = outside conv7's domain.
+int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan);
+void conv7_launch(const C7Plan& p, hipStream_t stream);

@@ -34,6 +34,9 @@ struct ConvFuse {
 // (the caller then takes the general kernels).
 int conv6_try_launch(const ConvArgs& a, const ConvFuse* fuse, int dtype, hipStream_t stream);
 
+// Whole-image streaming kernel for 32 x 32 maps (conv7.hip).  Same return convention.
+int conv7_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+
 // Split-bf16 variant for fp32 tensors (conv6s.hip): w = bf16 [hi | lo][g][tap][Cout][Cin], `wplane_elems` elements per plane.
 int conv6_split_try_launch(const ConvArgs& a, long wplane_elems, const ConvFuse* fuse, hipStream_t stream);
 
