@@ -11,6 +11,7 @@
 #include "conv6_common.h"
 #include "hdmoe.h"
 #include "conv6_body.h"
+#include "conv7_body.h"
 #include "wgrad6_body.h"
 #include "conv6s_body.h"
 
@@ -35,6 +36,28 @@ void launch_bwd6(const C6Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
   const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
   hipLaunchKernelGGL((bwd6_kernel<MT, NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
+}
+
+// The same with the whole-image streaming kernel (conv7_body.h) as the dgrad program: 32 x 32 maps, enough images to fill the chip.
+template <int CO, int KMASK, int TWS, int OT>
+__global__ __launch_bounds__(512) void bwd7_kernel(C7Args c, W6Args a3, W6Args a5, int G7, int ibs, int obs) {
+  const int b = blockIdx.x;
+  if (b < G7) { conv7_body<CO, KMASK>(c, b, G7); return; }
+  int r = b - G7;
+  const int bx = r % ibs; r /= ibs;
+  const int by = r % obs;
+  const int z = r / obs;
+  if (z < a3.chunks) wgrad6_body<3, TWS, OT, false>(a3, bx, by, z);
+  else wgrad6_body<5, TWS, OT, false>(a5, bx, by, z - a3.chunks);
+}
+
+template <int CO, int KMASK, int TWS, int OT>
+void launch_bwd7(const C7Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  const size_t lds = (size_t)C7_LDS > wp.lds ? (size_t)C7_LDS : wp.lds;
+  const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
+  hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
 }
 
 // The same for a router-trunk layer (fp32 tensors on the bf16 pipe: conv6_split program + wgrad6<SPLIT> program).
@@ -105,6 +128,18 @@ int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, flo
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) {
     const int s = g < ngroups ? g : 0;
     c.kh[g] = kh[s]; c.kw[g] = kw[s]; c.pt[g] = kh[s] - 1 - pt[s]; c.pl[g] = kw[s] - 1 - pl[s];
+  }
+  {
+    C7Plan cp7;                                            // 32 x 32 maps: the streaming kernel as the dgrad program (wgrad6 handles 3x3 / 5x5 only)
+    if (!conv7_plan(c, dtype, cp7) && cp7.kmask == 3) {
+#define BWD7_GO(Co)                                                                              \
+  do {                                                                                           \
+    if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd7<Co, 3, 5, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 5, 1>(cp7, wp, stream); } \
+    else { if (wp.OT == 2) launch_bwd7<Co, 3, 4, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 4, 1>(cp7, wp, stream); }            \
+  } while (0)
+      if (cp7.CO == 2) BWD7_GO(2); else BWD7_GO(1);
+      return hdmoe_launch_status();
+    }
   }
   C6Plan cp;
   if (conv6_plan(c, dtype, cp)) return 1;

@@ -1037,7 +1037,11 @@ BLK6 = _os.environ.get("HDMOE_BLK6", "1") != "0"
 # dropout 0.2; fused vs conv6 + film_silu + conv6): 32 -> 32 at 32x32 108 vs 117 us, 64 -> 32 140 vs 142, 32 -> 32 at 16x16 33 vs 42; but
 # 64 -> 64 at 16x16 76 vs 73, 128 -> 64 98 vs 93, 64 -> 64 at 32x32 306 vs 280: with 64 output channels the unit's phases (conv A, middle op,
 # conv B) run one after the other in a single 8-wave workgroup and the halo recompute is not paid back.  "c32": 32-channel blocks only.
+# Round 4: on 32 x 32 maps with enough routed rows the whole-image streaming kernel (csrc/conv7.hip) runs the two convs + the FiLM pass in
+# 2 x 27 + 19 us against the fused launch's 97-108 us, so "c32" leaves those blocks to it (same box: 14.00 -> 13.72 ms / step).
 BLK6_SCOPE = _os.environ.get("HDMOE_BLK6_SCOPE", "c32")
+CONV7 = _os.environ.get("HDMOE_CONV7", "1") != "0"
+C7_MINN = int(_os.environ.get("HDMOE_C7_MINN", "192"))
 
 
 def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, gain2: float, emb: Tensor, p: float, training: bool,
@@ -1062,7 +1066,7 @@ def unet_block_fused(h: Tensor, res: Optional[Tensor], w1s, w2s, gain1: float, g
     C = ent1.O
     if ent1.I != Cin or ent2.I != C or ent2.O != C or (seg is None and len(w1s) != 1):
         return None
-    if BLK6_SCOPE == "c32" and C != 32:
+    if BLK6_SCOPE == "c32" and (C != 32 or (CONV7 and H == 32 and W == 32 and N >= C7_MINN)):
         return None
     p = float(p) if training else 0.0
     e32 = _f32(emb)
