@@ -42,7 +42,7 @@ void launch_bwd6(const C6Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
 template <int CO, int KMASK, int TWS, int OT>
 __global__ __launch_bounds__(512) void bwd7_kernel(C7Args c, W6Args a3, W6Args a5, int G7, int ibs, int obs) {
   const int b = blockIdx.x;
-  if (b < G7) { conv7_body<CO, KMASK>(c, b, G7); return; }
+  if (b < G7) { conv7_body<CO, KMASK, TWS == 4>(c, b, G7); return; }
   int r = b - G7;
   const int bx = r % ibs; r /= ibs;
   const int by = r % obs;
@@ -55,7 +55,7 @@ template <int CO, int KMASK, int TWS, int OT>
 void launch_bwd7(const C7Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
   static bool attr = false;
   if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-  const size_t lds = (size_t)C7_LDS > wp.lds ? (size_t)C7_LDS : wp.lds;
+  const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
   const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
   hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
 }
@@ -131,7 +131,7 @@ int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, flo
   }
   {
     C7Plan cp7;                                            // 32 x 32 maps: the streaming kernel as the dgrad program (wgrad6 handles 3x3 / 5x5 only)
-    if (!conv7_plan(c, dtype, cp7) && cp7.kmask == 3) {
+    if (!conv7_plan(c, dtype, cp7) && cp7.kmask == 3 && (cp7.w16 != 0) == (wp.TWS == 4)) {
 #define BWD7_GO(Co)                                                                              \
   do {                                                                                           \
     if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd7<Co, 3, 5, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 5, 1>(cp7, wp, stream); } \

@@ -1,6 +1,6 @@
 // K3 (third generation): whole-image streaming convolution for the k x k expert layers on 32 x 32 feature maps -- forward and dgrad of
 // MP_Conv (reference models/model_internals.py:253-275), all experts of a layer in one launch (models/model_config1.py:25-37).
-// Design notes: conv7_body.h.  Domain: bf16, stride 1, H = W = 32, square k in {3, 5, 7} with "same" padding (k - 1) / 2,
+// Design notes: conv7_body.h.  Domain: bf16, stride 1, H = W = 32 or H = W = 16, square k in {3, 5, 7} with "same" padding (k - 1) / 2,
 // Cin % 32 == 0 (<= 256), Cout in {32, 64}, at least HDMOE_C7_MINN images (a unit is a whole image: fewer images than CUs leave CUs idle,
 // conv6's 256-pixel units fill the chip better then).  Everything else stays on conv6 / conv.hip.
 #include <stdlib.h>
@@ -10,8 +10,8 @@
 
 namespace {
 
-template <int CO, int KMASK>
-__global__ __launch_bounds__(512) void conv7_kernel(C7Args a) { conv7_body<CO, KMASK>(a, blockIdx.x, gridDim.x); }
+template <int CO, int KMASK, bool W16>
+__global__ __launch_bounds__(512) void conv7_kernel(C7Args a) { conv7_body<CO, KMASK, W16>(a, blockIdx.x, gridDim.x); }
 
 }  // namespace
 
@@ -22,7 +22,8 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
   if (off) return 1;
   if (dtype != HDMOE_BF16 || c.stride != 1 || c.ones || c.Cphys != c.Cin || c.Ipad != c.Cin || c.Cin % 32 || c.Cin > 256 || c.Cstore != c.Cout) return 1;
   if (c.Cout != 32 && c.Cout != 64) return 1;
-  if (c.H != 32 || c.W != 32 || c.Ho != 32 || c.Wo != 32 || c.N < minn) return 1;
+  const bool w16 = c.H == 16;
+  if (!((c.H == 32 && c.W == 32) || (c.H == 16 && c.W == 16)) || c.Ho != c.H || c.Wo != c.W || c.N < minn) return 1;
   int kmask = 0;
   long maxtaps = 0;
   for (int g = 0; g < c.ngroups; ++g) {
@@ -32,9 +33,9 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
     if ((long)k * k > maxtaps) maxtaps = (long)k * k;
   }
   if (((uintptr_t)c.x | (uintptr_t)c.w | (uintptr_t)c.y | (uintptr_t)c.res) & 15) return 1;
-  const long xbytes = (long)c.N * 1024 * c.Cin * 2;
+  const long xbytes = (long)c.N * c.H * c.W * c.Cin * 2;
   const long wbytes = ((long)(c.ngroups - 1) * c.wstride + maxtaps * c.Cout * c.Cin) * 2;
-  if (xbytes >= (1l << 31) || wbytes >= (1l << 31) || (long)c.N * 1024 * c.Cout >= (1l << 31)) return 1;
+  if (xbytes >= (1l << 31) || wbytes >= (1l << 31) || (long)c.N * c.H * c.W * c.Cout >= (1l << 31)) return 1;
   C7Args& a = plan.a;
   a.x = c.x; a.w = c.w; a.y = c.y; a.res = c.res; a.seg = c.seg; a.wstride = c.wstride;
   a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.ngroups = c.ngroups; a.alpha = c.alpha; a.beta = c.beta;
@@ -46,22 +47,26 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
     for (int k = i; k > 0 && a.ks[a.order[k]] > a.ks[a.order[k - 1]]; --k) { const int t = a.order[k]; a.order[k] = a.order[k - 1]; a.order[k - 1] = t; }
   static const long gcap_env = getenv("HDMOE_C7_G") ? atol(getenv("HDMOE_C7_G")) : 0;
   const long gcap = gcap_env > 0 ? gcap_env : 256;
-  plan.G = (unsigned)(c.N < gcap ? c.N : gcap);
+  const long units = w16 ? (c.N + 1) / 2 + c.ngroups : c.N;    // (16 x 16: pairs of images of one expert; an upper bound for any routing)
+  plan.G = (unsigned)(units < gcap ? units : gcap);
   plan.CO = c.Cout / 32;
+  plan.w16 = w16 ? 1 : 0;
+  plan.lds = w16 ? C7Lds<true>::BYTES : C7Lds<false>::BYTES;
   plan.kmask = (kmask & 4) ? 7 : 3;                          // instantiated kernel-size sets: {3, 5} and {3, 5, 7}
   return 0;
 }
 
-template <int CO, int KMASK>
+template <int CO, int KMASK, bool W16>
 static void conv7_launch_t(const C7Plan& p, hipStream_t stream) {
   static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)conv7_kernel<CO, KMASK>, hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS); }
-  hipLaunchKernelGGL((conv7_kernel<CO, KMASK>), dim3(p.G), dim3(512), C7_LDS, stream, p.a);
+  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)conv7_kernel<CO, KMASK, W16>, hipFuncAttributeMaxDynamicSharedMemorySize, C7Lds<W16>::BYTES); }
+  hipLaunchKernelGGL((conv7_kernel<CO, KMASK, W16>), dim3(p.G), dim3(512), C7Lds<W16>::BYTES, stream, p.a);
 }
 
 void conv7_launch(const C7Plan& p, hipStream_t stream) {
-  if (p.CO == 2) { if (p.kmask == 7) conv7_launch_t<2, 7>(p, stream); else conv7_launch_t<2, 3>(p, stream); }
-  else { if (p.kmask == 7) conv7_launch_t<1, 7>(p, stream); else conv7_launch_t<1, 3>(p, stream); }
+#define C7_GO(Co, Km) do { if (p.w16) conv7_launch_t<Co, Km, true>(p, stream); else conv7_launch_t<Co, Km, false>(p, stream); } while (0)
+  if (p.CO == 2) { if (p.kmask == 7) C7_GO(2, 7); else C7_GO(2, 3); }
+  else { if (p.kmask == 7) C7_GO(1, 7); else C7_GO(1, 3); }
 }
 
 int conv7_try_launch(const ConvArgs& c, int dtype, hipStream_t stream) {

@@ -26,38 +26,55 @@ typedef __attribute__((address_space(3))) void* c7_lptr_t;
 struct C7Args {
   const void* x; const void* w; void* y; const void* res; const int* seg;
   long wstride;                        // elements per group in the weight image [g][tap][Cout][Cin]
-  int N, Cin, Cout, ngroups;           // H = W = 32
+  int N, Cin, Cout, ngroups;           // H = W = 32 (or 16: conv7_body<.., .., true>)
   int ks[HDMOE_MAX_GROUPS], order[HDMOE_MAX_GROUPS];   // kernel size per group; groups in descending kernel size
   float alpha, beta;
   int xbytes, wbytes;
   int dbg;                             // development ablations: 1 skip the MFMAs, 2 skip the tile DMA of later units, 4 skip the stores
 };
 
-constexpr int C7_PITCH = 35;                                   // pixel slots per image row: 32 + 3 shared pad slots
-constexpr int C7_ROWB = C7_PITCH * 64;                         // bytes per row of a tile
-constexpr int C7_TILE = (32 * C7_PITCH + 3) * 64;              // 71,872 B: 32 rows + the pad behind the last one
-constexpr int C7_WBUF = 8192;                                  // one weight stage: 4 taps x 32 rows or 2 taps x 64 rows, 64 B each
-constexpr int C7_T0 = 2 * C7_WBUF;                             // tiles start behind the weight ring (keeps every row address >= 0)
-constexpr int C7_ZROW = C7_T0 + 2 * C7_TILE;                   // 38 zero pixel slots: what a row outside the image reads
-constexpr int C7_LDS = C7_ZROW + 38 * 64;                      // 162,560 B
+// Tile geometry.  32 x 32 maps: a tile is one image, [32 rows][35 pixel slots][64 B] (32 pixels + 3 pad slots shared with the next row), wave w
+// owns rows 4w .. 4w+3.  16 x 16 maps: a tile is TWO images of one expert stacked as 32 "virtual" rows of [19 slots][64 B] (rows 0-15 image A,
+// 16-31 image B; 16 * 19 slots = 304 = 0 mod 16, so a 32-lane fragment read -- lanes 0-15 a row of A, lanes 16-31 the same row of B --
+// keeps the bank pattern of 32 consecutive slots), wave w owns rows 2w, 2w+1 of both images.
+template <bool W16> struct C7Geo;
+template <> struct C7Geo<false> {
+  static constexpr int IMG = 32, MB = 4, ROWB = 35 * 64, TILE = (32 * 35 + 3) * 64, WBUF = 8192, TCO = 4, PPW = 8, HBOFF = 0;
+  static constexpr int ZBYTES = 38 * 64;
+};
+template <> struct C7Geo<true> {
+  static constexpr int IMG = 16, MB = 2, ROWB = 19 * 64, TILE = (32 * 19 + 3) * 64, WBUF = 28672, TCO = 14, PPW = 4, HBOFF = 16 * 19 * 64;
+  static constexpr int ZBYTES = HBOFF + 22 * 64;
+};
+template <bool W16> struct C7Lds {
+  using GEO = C7Geo<W16>;
+  static constexpr int T0 = 2 * GEO::WBUF;                     // tiles start behind the weight ring (keeps every row address >= 0)
+  static constexpr int ZROW = T0 + 2 * GEO::TILE;              // zero pixel slots: what a row outside the image reads
+  static constexpr int BYTES = ZROW + GEO::ZBYTES;             // 162,560 B / 156,416 B
+};
 
-// One stage = up to T consecutive kernel rows of one kernel column.
-template <int KS, int CO> struct C7Sched {
-  static constexpr int T = 4 / CO;
+// One stage = up to T = TCO / CO consecutive kernel rows of one kernel column (TCO: 2-KB weight blocks per ring buffer).
+template <int KS, int CO, int TCO> struct C7Sched {
+  static constexpr int T = TCO / CO;
   static constexpr int SPC = (KS + T - 1) / T;                 // stages per kernel column
   static constexpr int NS = KS * SPC;                          // stages per channel chunk
-  // taps of stage i of a column, balanced (5 -> 3 + 2, 7 -> 4 + 3 / 2 + 2 + 2 + 1)
+  // kernel rows of stage i of a column, balanced (5 -> 2 + 3, 7 -> 3 + 4 / 1 + 2 + 2 + 2)
   static constexpr int ky0(int i) { return (KS * i) / SPC; }
   static constexpr int nt(int i) { return (KS * (i + 1)) / SPC - (KS * i) / SPC; }
 };
 
-struct C7Unit { int g, n, ks; };
+struct C7Unit { int g, n, n2, ks; };
 
-#define C7_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int N> DEVI void c7_wait_barrier() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory"); }
 
-template <int CO, int KMASK>
+template <int CO, int KMASK, bool W16>
 DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 #if __HIP_DEVICE_COMPILE__
+  using GEO = C7Geo<W16>;
+  using L = C7Lds<W16>;
+  constexpr int MB = GEO::MB, IMG = GEO::IMG, ROWB = GEO::ROWB, TILE = GEO::TILE, WBUF = GEO::WBUF, TCO = GEO::TCO, PPW = GEO::PPW;
+  constexpr int T0 = L::T0, ZROW = L::ZROW;
+  constexpr int NSTORE = MB * CO * 2;                           // epilogue stores per wave
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,14 +84,14 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
   const int CI = a.Cin >> 5;
   const int cin2 = a.Cin * 2;
 
-  // ---- unit list: images of the groups in descending kernel size, dealt in a snake over the workgroups
+  // ---- unit list: images (pairs of images on 16 x 16 maps) of the groups in descending kernel size, dealt in a snake over the workgroups
   int cum[HDMOE_MAX_GROUPS + 1];
   cum[0] = 0;
 #pragma unroll
   for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) {
     int cnt = 0;
     if (i < a.ngroups) { const int g = a.order[i]; cnt = a.seg ? a.seg[g + 1] - a.seg[g] : a.N; }
-    cum[i + 1] = cum[i] + cnt;
+    cum[i + 1] = cum[i] + (W16 ? (cnt + 1) >> 1 : cnt);
   }
   const int total = cum[HDMOE_MAX_GROUPS];
   auto unit_at = [&](int q, C7Unit& u) -> bool {
@@ -89,47 +106,67 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
     int ks = 3;
 #pragma unroll
     for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == g) ks = a.ks[i];
-    u.g = g; u.ks = ks; u.n = (a.seg ? a.seg[g] : 0) + pos - base;
+    const int s0 = a.seg ? a.seg[g] : 0, s1 = a.seg ? a.seg[g + 1] : a.N;
+    u.g = g; u.ks = ks;
+    if (W16) { u.n = s0 + 2 * (pos - base); u.n2 = u.n + 1 < s1 ? u.n + 1 : -1; }
+    else { u.n = s0 + pos - base; u.n2 = -1; }
     return true;
   };
 
-  // ---- zero the pad slots of both tiles and the zero row (never written again: the DMA only touches data slots)
+  // ---- zero the pad slots of both tiles and the zero rows (never written again: the DMA only touches data slots)
   for (int i = tid; i < 33 * 12; i += 512) {
-    const int off = (i / 12) * C7_ROWB + (i % 12) * 16;
-    *reinterpret_cast<uint4*>(lds + C7_T0 + off) = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(lds + C7_T0 + C7_TILE + off) = make_uint4(0, 0, 0, 0);
+    const int off = (i / 12) * ROWB + (i % 12) * 16;
+    *reinterpret_cast<uint4*>(lds + T0 + off) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(lds + T0 + TILE + off) = make_uint4(0, 0, 0, 0);
   }
-  for (int i = tid; i < 38 * 4; i += 512) *reinterpret_cast<uint4*>(lds + C7_ZROW + i * 16) = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < GEO::ZBYTES / 16; i += 512) *reinterpret_cast<uint4*>(lds + ZROW + i * 16) = make_uint4(0, 0, 0, 0);
 
   // ---- per-lane constants
-  // tile DMA: lane i of a piece holds pixel i >> 2 (of 16), LDS slot i & 3; it fetches the source slot (i & 3) ^ key(position)
+  // tile DMA: lane i of a piece holds pixel i >> 2 (of 16) at row slot 3 + pixel (+ 16 in the right half of a 32-pixel row: same key),
+  // LDS chunk i & 3; it fetches the source chunk (i & 3) ^ key(slot)
   const int dpx = lane >> 2;
   const unsigned xlane = (unsigned)(dpx * cin2 + (((lane & 3) ^ (((3 + dpx) >> 2) & 3)) << 4));
-  // weight DMA: lane i holds output row i >> 2 (of 16), slot i & 3
+  // weight DMA: lane i holds output row i >> 2 (of 16), chunk i & 3
   const unsigned wlane = (unsigned)(dpx * cin2 + (((lane & 3) ^ ((dpx >> 2) & 3)) << 4));
-  // fragment reads: pixel column r + cc (cc = kernel column + 3 - pad, 0 .. 6), 16-channel k-step 0; k-step 1 = ^ 32
+  // fragment reads: row slot (lane's pixel column) + cc (cc = kernel column + 3 - pad, 0 .. 6), 16-channel k-step 0; k-step 1 = ^ 32
   int acol[7];
 #pragma unroll
-  for (int cc = 0; cc < 7; ++cc) { const int col = r + cc; acol[cc] = (col << 6) + ((h ^ ((col >> 2) & 3)) << 4); }
+  for (int cc = 0; cc < 7; ++cc) {
+    const int col = (W16 ? (r & 15) : r) + cc;
+    acol[cc] = (col << 6) + ((h ^ ((col >> 2) & 3)) << 4) + (W16 ? (r >> 4) * GEO::HBOFF : 0);
+  }
   const int wl = (r << 6) + ((h ^ ((r >> 2) & 3)) << 4);        // weight fragment of output row r, k-step 0
 
-  // issue this wave's 8 pieces (rows 4 wave .. 4 wave + 3, two halves each) of chunk c of image n into tile buffer tb
-  auto issue_tile = [&](int n, int c, int tb) {
-    const int lbase = C7_T0 + tb * C7_TILE + 3 * 64;
+  // issue this wave's pieces of chunk c of a unit's image(s) into tile buffer tb: 32 x 32: rows 4 wave .. + 3, two 16-pixel halves each;
+  // 16 x 16: rows 2 wave, 2 wave + 1 of both images (an absent second image reads as zeros: out-of-range offset)
+  auto issue_tile = [&](const C7Unit& u, int c, int tb) {
+    const int lbase = T0 + tb * TILE + 3 * 64;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = 4 * wave + (k >> 1), half = k & 1;
-      const int so = ((n * 32 + row) * 32 + half * 16) * cin2 + c * 64;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c7_lptr_t)(lds + lbase + row * C7_ROWB + half * 1024), 16, xlane, so, 0, 0);
+    for (int k = 0; k < PPW; ++k) {
+      if (W16) {
+        const int img = k >> 1, row = 2 * wave + (k & 1);
+        const int n = img ? u.n2 : u.n;
+        const int so = (n * 16 + row) * 16 * cin2 + c * 64;
+        const unsigned vo = n < 0 ? 0xFFFFFFFFu : xlane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c7_lptr_t)(lds + lbase + (img * 16 + row) * ROWB), 16, vo, n < 0 ? 0 : so, 0, 0);
+      } else {
+        const int row = 4 * wave + (k >> 1), half = k & 1;
+        const int so = ((u.n * 32 + row) * 32 + half * 16) * cin2 + c * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c7_lptr_t)(lds + lbase + row * ROWB + half * 1024), 16, xlane, so, 0, 0);
+      }
     }
   };
-  // this wave's piece of the weight stage (kernel column kx, rows ky0 .. ky0 + nt) of chunk c, group g, kernel size ks -> ring buffer sp
+  // this wave's pieces of the weight stage (kernel column kx, rows ky0 .. ky0 + nt) of chunk c, group g, kernel size ks -> ring buffer sp
   auto issue_wstage = [&](int g, int ks, int c, int kx, int ky0, int nt, int sp) {
-    const int ts = wave / (2 * CO), pc = wave % (2 * CO);       // tap slot, 16-row piece inside the tap
-    if (ts < nt) {
-      const int tap = (ky0 + ts) * ks + kx;
-      const int so = (int)(((long)g * a.wstride + (long)(tap * a.Cout + pc * 16) * a.Cin) * 2) + c * 64;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c7_lptr_t)(lds + sp * C7_WBUF + wave * 1024), 16, wlane, so, 0, 0);
+#pragma unroll
+    for (int j = 0; j < (2 * TCO + 7) / 8; ++j) {
+      const int pi = wave + 8 * j;
+      const int ts = pi / (2 * CO), pc = pi % (2 * CO);         // tap slot, 16-row piece inside the tap
+      if (ts < nt) {
+        const int tap = (ky0 + ts) * ks + kx;
+        const int so = (int)(((long)g * a.wstride + (long)(tap * a.Cout + pc * 16) * a.Cin) * 2) + c * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c7_lptr_t)(lds + sp * WBUF + pi * 1024), 16, wlane, so, 0, 0);
+      }
     }
   };
 
@@ -138,39 +175,39 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
   if (!unit_at(q, cur)) return;
   bool has_next = unit_at(q + 1, nxt);
   int tp = 0, sp = 0;                                           // tile / weight ring parity
-  auto nt0_of = [](int ks) { return ks == 3 ? C7Sched<3, CO>::nt(0) : (ks == 5 ? C7Sched<5, CO>::nt(0) : C7Sched<7, CO>::nt(0)); };
+  auto nt0_of = [](int ks) { return ks == 3 ? C7Sched<3, CO, GEO::TCO>::nt(0) : (ks == 5 ? C7Sched<5, CO, GEO::TCO>::nt(0) : C7Sched<7, CO, GEO::TCO>::nt(0)); };
   issue_wstage(cur.g, cur.ks, 0, 0, 0, nt0_of(cur.ks), 0);       // first stage of the unit's schedule: column 0, rows 0 .. nt0
-  issue_tile(cur.n, 0, 0);
+  issue_tile(cur, 0, 0);
   bool first = true;
 
-  // ---- one image: all chunks, all stages; prefetches the next image's first tile and first weight stage
+  // ---- one unit: all chunks, all stages; prefetches the next unit's first tile and first weight stage
   auto run_unit = [&](auto ks_tag) {
     constexpr int KS = decltype(ks_tag)::value;
-    using S = C7Sched<KS, CO>;
+    using S = C7Sched<KS, CO, TCO>;
     constexpr int P = (KS - 1) / 2, Q = 3 - P;
-    f32x16 acc[4][CO];
+    f32x16 acc[MB][CO];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int b = 0; b < CO; ++b) acc[m][b] = (f32x16)(0.f);
 
     for (int c = 0; c < CI; ++c) {
       const bool last_chunk = c == CI - 1;
       const bool tile_next = (!last_chunk || has_next) && !((a.dbg & 2) && last_chunk);   // a tile is fetched beside this chunk's first stage
-      const int tbase = C7_T0 + tp * C7_TILE;
+      const int tbase = T0 + tp * TILE;
 #pragma unroll
       for (int s = 0; s < S::NS; ++s) {
         const int kx = s / S::SPC, si = s % S::SPC;             // (compile-time after unrolling)
         const int ky0 = S::ky0(si), nt = S::nt(si);
-        // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free
+        // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free.
+        //      vmcnt counts in issue order: what may stay in flight is whatever this wave issued AFTER the pieces it needs now
         if (s == 0) {
-          // older than everything needed here: nothing but (first chunk of a later unit) the previous unit's 8 * CO epilogue stores
-          if (c == 0 && !first) { if (CO == 2) C7_WAIT_BARRIER(16); else C7_WAIT_BARRIER(8); }
-          else C7_WAIT_BARRIER(0);
+          if (c == 0 && !first) c7_wait_barrier<NSTORE>();      // the previous unit's epilogue stores
+          else c7_wait_barrier<0>();
         } else if (s == 1 && tile_next) {
-          C7_WAIT_BARRIER(8);                                   // the 8 tile pieces issued behind this stage's weight piece stay in flight
+          c7_wait_barrier<PPW>();                               // the tile pieces issued behind this stage's weight pieces
         } else {
-          C7_WAIT_BARRIER(0);
+          c7_wait_barrier<0>();
         }
         // ---- next stage's weights, next tile
         if (s + 1 < S::NS) {
@@ -182,19 +219,19 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
           issue_wstage(nxt.g, nxt.ks, 0, 0, 0, nt0_of(nxt.ks), sp ^ 1);
         }
         if (s == 0 && tile_next) {
-          if (!last_chunk) issue_tile(cur.n, c + 1, tp ^ 1); else issue_tile(nxt.n, 0, tp ^ 1);
+          if (!last_chunk) issue_tile(cur, c + 1, tp ^ 1); else issue_tile(nxt, 0, tp ^ 1);
         }
-        // ---- MFMAs of the stage: per 16-channel k-step, the nt + 3 input rows it touches, then per kernel row its weight fragment(s)
+        // ---- MFMAs of the stage: per 16-channel k-step, the nt + MB - 1 input rows it touches, then per kernel row its weight fragment(s)
         if (!(a.dbg & 1)) {
-          const int wb = sp * C7_WBUF;
-          const int row0 = 4 * wave - P + ky0;                  // image row of fragment j = 0
+          const int wb = sp * WBUF;
+          const int row0 = MB * wave - P + ky0;                 // image row of fragment j = 0
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2) {
-            bf16x8 xf[7];
+            bf16x8 xf[7 + MB - 1];
 #pragma unroll
-            for (int j = 0; j < nt + 3; ++j) {
+            for (int j = 0; j < nt + MB - 1; ++j) {
               const int row = row0 + j;
-              const int sb = ((unsigned)row < 32u) ? tbase + row * C7_ROWB : C7_ZROW;      // wave-uniform
+              const int sb = ((unsigned)row < (unsigned)IMG) ? tbase + row * ROWB : ZROW;  // wave-uniform
               xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((acol[kx + Q] ^ (k2 << 5)) + sb));
             }
 #pragma unroll
@@ -204,7 +241,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
               for (int b = 0; b < CO; ++b)
                 wf[b] = *reinterpret_cast<const bf16x8*>(lds + wb + (i * CO + b) * 2048 + (wl ^ (k2 << 5)));
 #pragma unroll
-              for (int m = 0; m < 4; ++m)
+              for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int b = 0; b < CO; ++b)
                   acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b], xf[m + i], acc[m][b], 0, 0, 0);
@@ -219,9 +256,12 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
     if (!(a.dbg & 4)) {
       bf16* Y = (bf16*)a.y;
       const bf16* R = (const bf16*)a.res;
+      const int nimg = W16 ? ((r >> 4) ? cur.n2 : cur.n) : cur.n;
+      const bool live = !W16 || nimg >= 0;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const long pix = (((long)cur.n * 32 + 4 * wave + m) * 32 + r) * a.Cout;
+      for (int m = 0; m < MB; ++m) {
+        const long pix = W16 ? (((long)nimg * 16 + 2 * wave + m) * 16 + (r & 15)) * a.Cout
+                             : (((long)nimg * 32 + 4 * wave + m) * 32 + r) * a.Cout;
 #pragma unroll
         for (int b = 0; b < CO; ++b)
 #pragma unroll
@@ -229,7 +269,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = a.alpha * acc[m][b][8 * p + e];
-            if (R) {
+            if (R && live) {
               const long o0 = pix + 32 * b + 16 * p + 4 * h;
               const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);
               const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
@@ -242,12 +282,12 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
             const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
             const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
             const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
-            *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (live) *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
       }
     } else {
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int b = 0; b < CO; ++b) asm volatile("" :: "v"(acc[m][b]));
     }
@@ -269,7 +309,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 }  // namespace
 
 struct ConvArgs;
-struct C7Plan { C7Args a; unsigned G; int CO, kmask; };
+struct C7Plan { C7Args a; unsigned G; int CO, kmask, w16; size_t lds; };
 // Launch geometry of conv7 for one layer (conv7.hip; shared with the fused backward launch).  0 = planned, 1 = outside conv7's domain.
 int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan);
 void conv7_launch(const C7Plan& p, hipStream_t stream);

@@ -25,6 +25,17 @@ if "--check" in sys.argv:
     ]
     for N, Cin, Cout, ks, split, res in cases:
         ok &= c6.check(N, 32, Cin, Cout, ks, split, res, seed=N)
+    cases16 = [
+        (16, 64, 64, (3, 3, 5, 5), (3, 7, 12, 16), True),       # odd group sizes: pairs with an absent second image
+        (13, 32, 32, (5, 3), (4, 13), False),
+        (9, 128, 64, (3, 5), (5, 9), True),
+        (10, 96, 64, (3, 3, 5, 5), (2, 2, 7, 10), False),
+        (11, 64, 64, (3, 5, 7), (4, 8, 11), True),
+        (6, 64, 32, (5, 7), (6, 6), False),
+        (301, 64, 64, (3, 3, 5, 5), (70, 151, 210, 301), True),
+    ]
+    for N, Cin, Cout, ks, split, res in cases16:
+        ok &= c6.check(N, 16, Cin, Cout, ks, split, res, seed=N + 1)
     print("ALL OK" if ok else "FAILURES", flush=True)
 if "--time" in sys.argv:
     for Cin, Cout in ((32, 32), (64, 64), (96, 32), (64, 32)):
@@ -33,4 +44,8 @@ if "--time" in sys.argv:
     c6.timeit(512, 32, 32, 32, (5, 5, 5, 5))
     c6.timeit(256, 32, 32, 32, (3, 3, 5, 5))
     c6.timeit(1024, 32, 32, 32, (3, 3, 5, 5))
+    for Cin, Cout in ((64, 64), (128, 64), (96, 64), (32, 32)):
+        c6.timeit(512, 16, Cin, Cout, (3, 3, 5, 5))
+    c6.timeit(512, 16, 64, 64, (3, 3, 3, 3))
+    c6.timeit(512, 16, 64, 64, (5, 5, 5, 5))
 sys.exit(0 if ok else 1)
