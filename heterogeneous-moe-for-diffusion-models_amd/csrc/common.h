@@ -12,6 +12,7 @@
 #define HDMOE_F32 0
 #define HDMOE_BF16 1
 #define HDMOE_F32S 2     /* fp32 tensors, split-bf16 arithmetic: weight images are bf16 [hi | lo] planes */
+#define HDMOE_F16 3      /* hdmoe_cast only: fp16 tensors at the module boundary (converted at ingest / egress) */
 
 #define HDMOE_MAX_GROUPS 8
 #define MP_SILU_DIV 0.596f

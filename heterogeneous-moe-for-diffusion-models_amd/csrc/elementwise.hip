@@ -36,6 +36,57 @@ template <typename TI, typename TO>
 __global__ void cast_kernel(TO* out, const TI* x, long n) {
   GRID_STRIDE(i, n) out[i] = from_f<TO>(to_f(x[i]));
 }
+// fp16 exists at the module boundary only (`.half()` callers, reference tests/test_model/test_Unet_expert.py:106-115): converted to fp32
+// at ingest and back at egress, the arithmetic in between is fp32 / bf16
+__global__ void cast_h2f_kernel(float* out, const _Float16* x, long n) { GRID_STRIDE(i, n) out[i] = (float)x[i]; }
+__global__ void cast_f2h_kernel(_Float16* out, const float* x, long n) { GRID_STRIDE(i, n) out[i] = (_Float16)x[i]; }
+// Separable FIR resampling with an even-length filter f (resample(x, f, mode), reference model_internals.py:95-127), channel-last:
+//   down: y[oy][ox] = scale * sum_{i,j} k[i] k[j] x[2 oy - pad + i][2 ox - pad + j]           (F.conv2d, stride 2, padding pad, depthwise)
+//   up:   y[oy][ox] = scale * sum over (iy, i) with 2 iy - pad + i == oy (and likewise in x) of k[i] k[j] x[iy][ix]   (F.conv_transpose2d)
+// each is the other's adjoint, so the same two kernels serve the backward passes (with the other one's scale).
+struct FirTaps { float k[8]; };
+template <typename T>
+__global__ void fir_down_kernel(T* y, const T* x, FirTaps f, int L, int pad, float scale, int H, int W, int Ho, int Wo, int C, long total) {
+  GRID_STRIDE(e, total) {
+    const int c = (int)(e % C); long t = e / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); const long n = t / Ho;
+    float acc = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const int iy = 2 * oy - pad + i;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int j = 0; j < L; ++j) {
+        const int ix = 2 * ox - pad + j;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        acc += f.k[i] * f.k[j] * to_f(x[((n * H + iy) * W + ix) * C + c]);
+      }
+    }
+    y[e] = from_f<T>(scale * acc);
+  }
+}
+template <typename T>
+__global__ void fir_up_kernel(T* y, const T* x, FirTaps f, int L, int pad, float scale, int H, int W, int Ho, int Wo, int C, long total) {
+  GRID_STRIDE(e, total) {                                    // (H, W): input size; (Ho, Wo): output size
+    const int c = (int)(e % C); long t = e / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); const long n = t / Ho;
+    float acc = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const int ty = oy + pad - i;
+      if (ty < 0 || (ty & 1)) continue;
+      const int iy = ty >> 1;
+      if (iy >= H) continue;
+      for (int j = 0; j < L; ++j) {
+        const int tx = ox + pad - j;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ix = tx >> 1;
+        if (ix >= W) continue;
+        acc += f.k[i] * f.k[j] * to_f(x[((n * H + iy) * W + ix) * C + c]);
+      }
+    }
+    y[e] = from_f<T>(scale * acc);
+  }
+}
 template <typename T>
 __global__ void mp_silu_fwd_kernel(T* out, const T* x, long n) {
   GRID_STRIDE(i, n) out[i] = from_f<T>(mp_silu_f(to_f(x[i])));
@@ -923,8 +974,22 @@ int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, hipStrea
   else if (dt_in == HDMOE_BF16 && dt_out == HDMOE_F32) L1D((cast_kernel<bf16, float>), n, (float*)out, (const bf16*)x, n);
   else if (dt_in == HDMOE_F32 && dt_out == HDMOE_F32) L1D((cast_kernel<float, float>), n, (float*)out, (const float*)x, n);
   else if (dt_in == HDMOE_BF16 && dt_out == HDMOE_BF16) L1D((cast_kernel<bf16, bf16>), n, (bf16*)out, (const bf16*)x, n);
+  else if (dt_in == HDMOE_F16 && dt_out == HDMOE_F32) L1D(cast_h2f_kernel, n, (float*)out, (const _Float16*)x, n);
+  else if (dt_in == HDMOE_F32 && dt_out == HDMOE_F16) L1D(cast_f2h_kernel, n, (_Float16*)out, (const float*)x, n);
   else return HDMOE_EDTYPE;
   return hdmoe_launch_status();
+}
+/* up == 0: y (N, Ho, Wo, C) = scale * stride-2 depthwise correlation of x (N, H, W, C) with outer(k, k), padding `pad`;
+ * up == 1: the transposed operation (x is the small tensor).  taps: L <= 8 host floats (already normalised by the caller). */
+int hdmoe_fir_resample(void* y, const void* x, const float* taps, int L, int pad, float scale, int up, int N, int H, int W, int Ho, int Wo, int C,
+                       int dtype, hipStream_t stream) {
+  if (!y || !x || !taps || L < 1 || L > 8 || pad < 0 || N < 0) return HDMOE_EINVAL;
+  FirTaps f;
+  for (int i = 0; i < 8; ++i) f.k[i] = i < L ? taps[i] : 0.f;
+  const long total = (long)N * Ho * Wo * C;
+  if (total == 0) return HDMOE_OK;
+  DT_SWITCH(dtype, if (up) L1D(fir_up_kernel<T>, total, (T*)y, (const T*)x, f, L, pad, scale, H, W, Ho, Wo, C, total);
+                   else L1D(fir_down_kernel<T>, total, (T*)y, (const T*)x, f, L, pad, scale, H, W, Ho, Wo, C, total))
 }
 int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x)) L1D(mp_silu_fwd_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, n / VT<T>::W);

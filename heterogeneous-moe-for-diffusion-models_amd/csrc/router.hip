@@ -180,8 +180,18 @@ __global__ void combine_rows_bwd_kernel(T* dys, float* dsparse, const T* dout, c
   }
 }
 
+// counts ACCUMULATE: several forwards may share one optimizer step (gradient accumulation); FusedAdamW.step clears them behind the update
 __global__ void seg_counts_kernel(float* counts, const int* seg, int E) {
-  if ((int)threadIdx.x < E) counts[threadIdx.x] = (float)(seg[threadIdx.x + 1] - seg[threadIdx.x]);
+  if ((int)threadIdx.x < E) counts[threadIdx.x] += (float)(seg[threadIdx.x + 1] - seg[threadIdx.x]);
+}
+// the same from the sparse gate weights (B, E) when no dispatch plan exists (experts evaluated on the whole batch): rows with weight > 0
+__global__ void route_counts_kernel(float* counts, const float* sparse, int B, int E) {
+  const int e = blockIdx.x;
+  float c = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) c += sparse[(long)b * E + e] > 0.f ? 1.f : 0.f;
+  __shared__ float sm[16];
+  c = block_sum(c, sm);
+  if (threadIdx.x == 0) counts[e] += c;
 }
 
 }  // namespace
@@ -211,6 +221,11 @@ int hdmoe_dispatch_plan(int* perm, int* row_expert, float* row_w, int* inv, int*
 int hdmoe_seg_counts(float* counts, const int* seg, int E, hipStream_t stream) {
   if (!counts || !seg || E < 1 || E > 64) return HDMOE_EINVAL;
   hipLaunchKernelGGL(seg_counts_kernel, dim3(1), dim3(64), 0, stream, counts, seg, E);
+  return hdmoe_launch_status();
+}
+int hdmoe_route_counts(float* counts, const float* sparse, int B, int E, hipStream_t stream) {
+  if (!counts || !sparse || B < 1 || E < 1 || E > 64) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(route_counts_kernel, dim3(E), dim3(256), 0, stream, counts, sparse, B, E);
   return hdmoe_launch_status();
 }
 int hdmoe_gather_rows(void* dst, const void* src, const int* perm, long R, long L, int dtype, hipStream_t stream) {

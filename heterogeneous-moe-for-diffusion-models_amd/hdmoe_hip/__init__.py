@@ -11,6 +11,7 @@ import torch
 from . import _lib, ops                                    # noqa: F401
 from ._lib import LIB_PATH, lib                            # noqa: F401
 from .ops import manual_seed                               # noqa: F401
+from .bank import invalidate_weights                       # noqa: F401
 
 _policy = {"compute_dtype": torch.float32}
 

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HDMOE_LIB_PATH") or os.path.join(_HERE, "libhdmoe_hip.so")   # (override: development ablation builds)
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 3                   # (F16: hdmoe_cast only -- fp16 tensors are converted at the module boundary)
 MAX_GROUPS = 8
 
 # one letter per argument:
@@ -23,7 +23,7 @@ MAX_GROUPS = 8
 # The table is derived from include/hdmoe.h itself, so the binding cannot drift from the declared C ABI.
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "hdmoe.h"))
 _HOST_INT_ARRAYS = {"kh", "kw", "pt", "pl", "lens", "sb", "dims"}
-_HOST_FLOAT_ARRAYS = {"group_lr", "group_wd", "src_scale"}
+_HOST_FLOAT_ARRAYS = {"group_lr", "group_wd", "src_scale", "taps"}
 
 
 def _parse_header(path: str) -> dict:
@@ -90,6 +90,11 @@ def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.bfloat16:
         return BF16
     raise TypeError(f"hdmoe_hip kernels support float32 and bfloat16 activations, got {dt}")
+
+
+def dtype_code_cast(dt: torch.dtype) -> int:
+    """dtype codes hdmoe_cast accepts: float16 as well (module-boundary conversion of `.half()` tensors)."""
+    return F16 if dt == torch.float16 else dtype_code(dt)
 
 
 def _ptr(t):

@@ -47,6 +47,14 @@ def note_weights_changed() -> None:
     WEIGHTS_EPOCH += 1
 
 
+def invalidate_weights() -> None:
+    """Call after writing parameters behind autograd's back -- ``p.data.copy_()`` / ``lerp_`` / ``mul_`` (the usual EMA idiom) or a
+    loader that assigns through ``.data`` do not bump ``Tensor._version`` -- so that the next eval-mode forward re-prepares the weight
+    images.  (``load_state_dict``, in-place ops on the parameter itself, ``FusedAdamW.step`` and the train-mode forward are tracked
+    automatically; ``EDM_Sampler.sample`` additionally compares a device-side checksum of the parameters before replaying its graph.)"""
+    note_weights_changed()
+
+
 DEFER_FINISH = False
 STAGE = None                                              # name of the running backward section (graph.Stager)
 PENDING: list = []
@@ -104,6 +112,7 @@ class WeightBank:
         self._cb_queued = False
         self._keep: list = []
         self._prep_sig = None                                # signature of the parameters the current EVAL-mode images were prepared from
+        self._prep_sum = None                                # their content checksum (refresh_eval)
         if lib().hdmoe_wbank_desc_bytes() != _DESC.itemsize:
             raise RuntimeError("WBDesc layout mismatch between csrc/wbank.hip and hdmoe_hip/bank.py")
 
@@ -231,12 +240,38 @@ class WeightBank:
                 return
         call("hdmoe_wbank_prep", self._descs, self._rows, self._nrows, 1 if training else 0)
         self._prep_sig = sig                                 # (None after a train-mode prepare: it mutates the stored weights)
+        if training:
+            self._prep_sum = None
+
+    def invalidate(self):
+        """Forget the eval-mode weight images: the next forward prepares them again (see `invalidate_weights`)."""
+        self._prep_sig = None
+        self._prep_sum = None
+
+    def _content_sum(self) -> float:
+        """Sum of squares of every registered parameter (one multi-tensor launch + one 4-byte read): catches writes that neither bump
+        Tensor._version nor WEIGHTS_EPOCH (`p.data.copy_`, a loader assigning through .data).  Host-synchronous: used where a sync
+        is cheap -- once per EDM_Sampler.sample(), not per forward."""
+        from . import optim as _optim
+        params = [p for e in self.entries.values() for p in e.params]
+        ents = [(p, p, None, None, 0) for p in params]
+        tab = getattr(self, "_sum_tab", None)
+        sig = tuple(p.data_ptr() for p in params)
+        if tab is None or tab[0] != sig:
+            tab = self._sum_tab = (sig, _optim._Table(ents))
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        call("hdmoe_mt_sumsq", out, tab[1].descs, tab[1].chunks, tab[1].n, tab[1].ws)
+        return float(out.item())
 
     def refresh_eval(self):
         """Bring the eval-mode weight images up to date outside any captured graph (a hipGraph captured while the images were current
-        holds no prepare launch: EDM_Sampler calls this once per sample() before replaying)."""
+        holds no prepare launch: EDM_Sampler calls this once per sample() before replaying).  Compares the parameters' CONTENT too."""
         if self.entries:
+            cs = self._content_sum()
+            if cs != self._prep_sum:
+                self._prep_sig = None
             self.begin_step(False)
+            self._prep_sum = cs
             deactivate()
 
     def note_backward(self, ent: Entry):

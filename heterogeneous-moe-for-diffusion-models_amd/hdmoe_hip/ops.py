@@ -13,6 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import bank as _bank
+from ._lib import dtype_code_cast  # noqa: F401
 from ._lib import call, dtype_code
 
 Tensor = torch.Tensor
@@ -417,6 +418,8 @@ class _MPConvFn(torch.autograd.Function):
             wd = torch.empty(planes * G * wdstride, dtype=wdt, device=x.device) if ctx.needs_input_grad[0] else None
             call("hdmoe_wprep_fwd", list(weights), gains, gain_val, khs, kws, G, O, I, Ipad, Opad, wf, wstride, wd, wdstride,
                  1 if normalize else 0, 1 if training else 0, 1, dtc)
+            if training and normalize:                         # the train-mode forward re-normalises the stored weights in place (raw pointers:
+                _bank.note_weights_changed()                   #  Tensor._version stays) -- eval-mode images prepared earlier are stale
         ctx.wd = wd
         ctx.ent = ent
         ctx.bank = _bank.ACTIVE if ent is not None else None
@@ -573,6 +576,52 @@ class _MPConvFn(torch.autograd.Function):
         return (dx, dres, None, None, *dws, *dgs)
 
 
+class _StridedConvFn(torch.autograd.Function):
+    """MP_Conv with stride > 1 (reference model_internals.py:272-275: F.conv2d(x, w, padding=k // 2, stride)).  No reference model uses
+    it; forward and weight gradient run on the general strided kernels (the patch embedding's), the input gradient is not implemented."""
+
+    @staticmethod
+    def forward(ctx, x, w, gain, stride, training):
+        x = _c(x)
+        N, H, W, C = x.shape
+        O, I, kh, kw = (int(v) for v in w.shape)
+        if I != C:
+            raise RuntimeError(f"MP_Conv: input has {C} channels, weight expects {I}")
+        pad = kw // 2                                          # the reference pads both axes by the last kernel dim
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        Ipad = (I + 15) // 16 * 16
+        wf = torch.empty(kh * kw * O * Ipad, dtype=x.dtype, device=x.device)
+        call("hdmoe_wprep_fwd", [w], None, float(gain), [kh], [kw], 1, O, I, Ipad, 16, wf, wf.numel(), None, 0, 1, 1 if training else 0, 1, _dt(x))
+        if training:
+            _bank.note_weights_changed()
+        y = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
+        call("hdmoe_conv_fwd", x, wf, y, None, 1.0, 0.0, None, 1, wf.numel(), N, H, W, Ho, Wo, I, I, Ipad, O, O, stride, 0, [kh], [kw], [pad], [pad], _dt(x))
+        ctx.save_for_backward(x, w)
+        ctx.meta = (float(gain), stride, pad, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        gain, stride, pad, Ho, Wo = ctx.meta
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("MP_Conv(stride > 1): the input gradient is not implemented (no reference model uses a strided MP_Conv)")
+        N, H, W, C = x.shape
+        O, I, kh, kw = (int(v) for v in w.shape)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            Gs = [_zeros((kh * kw, O, I), torch.float32, x.device)]
+            call("hdmoe_conv_wgrad", x, _c(dy), Gs, None, 1, N, H, W, Ho, Wo, I, I, O, stride, 0, [kh], [kw], [pad], [pad], _dt(x))
+            dw = torch.empty_like(w)
+            call("hdmoe_wprep_bwd", [w], None, gain, Gs, [dw], None, [kh], [kw], 1, O, I, 1)
+        return None, dw, None, None, None
+
+
+def mp_conv_strided(x: Tensor, w: Tensor, gain: float, stride: int, training: bool = False) -> Tensor:
+    (w,) = f32_params([w])
+    return _StridedConvFn.apply(x, w, float(gain), int(stride), bool(training))
+
+
 _PRECOMP = None                           # output tensor a fused launch has already produced for the NEXT _MPConvFn.forward (ops.unet_block_fused)
 F32S = 2                                  # C-ABI dtype code: fp32 tensors, split-bf16 arithmetic (include/hdmoe.h HDMOE_F32S)
 # The fp32 router trunks run on the bf16 matrix pipe as split-bf16 (3 MFMAs per product, ~1e-5 relative): HDMOE_ROUTER_SPLIT=0
@@ -598,12 +647,12 @@ def mp_conv(x: Tensor, weights, gain=1.0, *, seg: Optional[Tensor] = None, res: 
     ``x``: (N,H,W,C) -> (N,Ho,Wo,O);  (N,S,C) -> (N,S,O);  (M,C) -> (M,O).  ``weights``: a tensor, or a list of
     per-expert tensors together with ``seg`` (device int32 row offsets) for a grouped launch.
     ``gain``: python float, a 0-dim float32 tensor (learnable out_gain), or a list of such tensors (one per group)."""
-    ws = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+    ws = f32_params(list(weights) if isinstance(weights, (list, tuple)) else [weights])
     G = len(ws)
     if isinstance(gain, (list, tuple)):
-        gts, gain_val = list(gain), 1.0
+        gts, gain_val = f32_params(list(gain)), 1.0
     elif torch.is_tensor(gain):
-        gts, gain_val = [gain] * G, 1.0
+        gts, gain_val = f32_params([gain]) * G, 1.0
     else:
         gts, gain_val = [], float(gain)
     shape = x.shape
@@ -888,19 +937,29 @@ class _CastFn(torch.autograd.Function):
         x = _c(x)
         ctx.src = x.dtype
         out = torch.empty(x.shape, dtype=dtype, device=x.device)
-        call("hdmoe_cast", out, x, x.numel(), _dt(x), dtype_code(dtype))
+        call("hdmoe_cast", out, x, x.numel(), dtype_code_cast(x.dtype), dtype_code_cast(dtype))
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
         dx = torch.empty(g.shape, dtype=ctx.src, device=g.device)
-        call("hdmoe_cast", dx, g, g.numel(), _dt(g), dtype_code(ctx.src))
+        call("hdmoe_cast", dx, g, g.numel(), dtype_code_cast(g.dtype), dtype_code_cast(ctx.src))
         return dx, None
 
 
 def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
-    return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+    """Element type conversion.  float16 is accepted at the module boundary only (fp16 <-> fp32; the kernels compute in fp32 / bf16)."""
+    if x.dtype == dtype:
+        return x
+    if torch.float16 in (x.dtype, dtype) and torch.bfloat16 in (x.dtype, dtype):
+        return _CastFn.apply(_CastFn.apply(x, torch.float32), dtype)
+    return _CastFn.apply(x, dtype)
+
+
+def f32_params(ts):
+    """fp16 parameters (a module after `.half()`) as fp32 tensors for the kernels; gradients flow back in fp16."""
+    return [cast(t, torch.float32) if torch.is_tensor(t) and t.dtype == torch.float16 else t for t in ts]
 
 
 class _MPSiluFn(torch.autograd.Function):
@@ -1297,15 +1356,56 @@ class _ResampleFn(torch.autograd.Function):
         return dx, None
 
 
-def resample(x: Tensor, mode: str = "keep") -> Tensor:
-    """f=[1,1] resample (model_internals.py:95-127): 'down' = 2x2 mean, 'up' = nearest x2."""
+class _FirResampleFn(torch.autograd.Function):
+    """resample(x, f, mode) for an even-length filter other than [1, 1] (model_internals.py:95-127): depthwise stride-2 correlation
+    with outer(f, f) / f.sum()^2 ('down') or its transpose with 4x the taps ('up'); each is the other's backward."""
+
+    @staticmethod
+    def forward(ctx, x, taps, mode):
+        x = _c(x)
+        N, H, W, C = x.shape
+        L = len(taps)
+        pad = (L - 1) // 2
+        if mode == "down":
+            Ho, Wo = (H + 2 * pad - L) // 2 + 1, (W + 2 * pad - L) // 2 + 1
+            out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+            call("hdmoe_fir_resample", out, x, taps, L, pad, 1.0, 0, N, H, W, Ho, Wo, C, _dt(x))
+        else:
+            Ho, Wo = (H - 1) * 2 - 2 * pad + L, (W - 1) * 2 - 2 * pad + L
+            out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+            call("hdmoe_fir_resample", out, x, taps, L, pad, 4.0, 1, N, H, W, Ho, Wo, C, _dt(x))
+        ctx.meta = (taps, mode, L, pad, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        taps, mode, L, pad, H, W = ctx.meta
+        g = _c(g)
+        N, Hg, Wg, C = g.shape
+        dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+        if mode == "down":                                     # transpose of the strided correlation (no 4x)
+            call("hdmoe_fir_resample", dx, g, taps, L, pad, 1.0, 1, N, Hg, Wg, H, W, C, _dt(g))
+        else:
+            call("hdmoe_fir_resample", dx, g, taps, L, pad, 4.0, 0, N, Hg, Wg, H, W, C, _dt(g))
+        return dx, None, None
+
+
+def resample(x: Tensor, mode: str = "keep", f=(1, 1)) -> Tensor:
+    """resample (model_internals.py:95-127), channel-last.  f = [1, 1]: 'down' = 2x2 mean, 'up' = nearest x2 (vector kernels);
+    any other even-length filter with up to 8 taps: the generic separable FIR kernels."""
     if mode == "keep":
         return x
     if mode not in ("down", "up"):
         raise ValueError(f"Invalid mode: {mode}")
-    if mode == "down" and (x.shape[1] % 2 or x.shape[2] % 2):
-        raise RuntimeError("resample('down') needs even spatial dims")
-    return _ResampleFn.apply(x, mode)
+    f = [float(v) for v in f]
+    if len(f) % 2 or not f:
+        raise AssertionError("resample: the filter must be 1-D with an even number of taps")
+    if f == [1.0, 1.0] and not (mode == "down" and (x.shape[1] % 2 or x.shape[2] % 2)):
+        return _ResampleFn.apply(x, mode)
+    if len(f) > 8:
+        raise NotImplementedError("resample: filters with more than 8 taps are not implemented")
+    tot = sum(f)
+    return _FirResampleFn.apply(x, tuple(v / tot for v in f), mode)
 
 
 class _SeqReduceFn(torch.autograd.Function):

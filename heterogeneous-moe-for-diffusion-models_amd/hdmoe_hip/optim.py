@@ -179,6 +179,14 @@ class FusedAdamW(torch.optim.Optimizer):
         call("hdmoe_mt_adamw", self._table.descs, self._table.chunks, self._table.n, self._table.ntensors, ss, max_norm,
              [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups], len(self.param_groups),
              g0["betas"][0], g0["betas"][1], g0["eps"])
+        # the routed-row counters of the tracked expert lists accumulate over the forwards of a step (models/_assembly.py): start the next one at zero
+        seen = set()
+        for lst, _ in self._usage.values():
+            if id(lst) not in seen:
+                seen.add(id(lst))
+                u = getattr(lst, "_hdmoe_usage", None)
+                if u is not None:
+                    u.zero_()
         return loss
 
     def load_state_dict(self, state_dict):

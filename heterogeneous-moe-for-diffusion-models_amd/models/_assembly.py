@@ -35,8 +35,10 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
     E = len(mods)
 
     def note_usage(plan):
-        # rows routed to each expert this step, for the optimizer: an expert without a sample is left out of the update like a grad-None
-        # tensor in the reference loop (hdmoe_hip/optim.py FusedAdamW.track_expert_usage)
+        # rows routed to each expert since the last optimizer step, for the optimizer: an expert without a sample is left out of the update
+        # like a grad-None tensor in the reference loop (hdmoe_hip/optim.py FusedAdamW.track_expert_usage).  Every dispatch path writes
+        # them -- a pre-installed counter that stayed zero would freeze the expert's parameters -- and they accumulate over the forwards
+        # of a step (FusedAdamW.step clears them behind the update).
         if torch.is_grad_enabled() and isinstance(experts, nn.ModuleList):
             u = getattr(experts, "_hdmoe_usage", None)
             if u is None or u.device != x.device or u.numel() != E:
@@ -44,7 +46,11 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
                     return
                 u = torch.zeros(E, dtype=torch.float32, device=x.device)
                 object.__setattr__(experts, "_hdmoe_usage", u)
-            ops.call("hdmoe_seg_counts", u, plan.seg, E)
+            if plan is not None:
+                ops.call("hdmoe_seg_counts", u, plan.seg, E)
+            else:
+                sp = out_router.detach()
+                ops.call("hdmoe_route_counts", u, sp if sp.dtype == torch.float32 and sp.is_contiguous() else sp.float().contiguous(), sp.shape[0], E)
 
     if all(isinstance(e, m.Unet_expert) for e in mods) and E <= 8:
         plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
@@ -64,7 +70,23 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
         ys = m.vit_expert_bank_forward(mods, xs, ts, tx, plan.seg)
         return ops.combine_rows(ys, out_router, plan)
+    note_usage(None)
     return _combine_weighted(_run_experts(x, mods, time_emb, text2d), out_router)
+
+
+def _note_usage_sparse(experts: nn.ModuleList, out_router: Tensor) -> None:
+    """Per-expert routed-row counts from the sparse gate weights (the path without a dispatch plan); see _dispatch_nhwc.note_usage."""
+    if not (torch.is_grad_enabled() and isinstance(experts, nn.ModuleList)):
+        return
+    E = len(experts)
+    u = getattr(experts, "_hdmoe_usage", None)
+    if u is None or u.device != out_router.device or u.numel() != E:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        u = torch.zeros(E, dtype=torch.float32, device=out_router.device)
+        object.__setattr__(experts, "_hdmoe_usage", u)
+    sp = out_router.detach()
+    ops.call("hdmoe_route_counts", u, sp if sp.dtype == torch.float32 and sp.is_contiguous() else sp.float().contiguous(), sp.shape[0], E)
 
 
 def _run_experts(x: Tensor, mods: List[nn.Module], time_emb: Tensor, text2d: Optional[Tensor]):
@@ -238,6 +260,7 @@ class _HDMOEMBase(nn.Module):
             w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_unet, te, Unet_router_mask, zeta)
             out_u = _dispatch_nhwc(ops.cast(in_unet, cdt), self.Unet_experts, w_unet, te, text2d, kcap=self.top_k)
             if vit_job is not None:
+                _note_usage_sparse(self.VIT_experts, w_vit)
                 out_v = _combine_weighted(vit_job, w_vit)
             else:
                 out_v = _dispatch_nhwc(ops.cast(in_vit, cdt), self.VIT_experts, w_vit, te, text2d, kcap=self.top_k)

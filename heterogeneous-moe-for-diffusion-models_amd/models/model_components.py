@@ -299,9 +299,15 @@ class Unet_expert(nn.Module):
         self.out_conv = m.MP_Conv(in_channels=self.out_channels, out_channels=img_channels, kernel=kernel_size)
 
     def forward(self, x: Tensor, time_emb: Tensor, text_emb: Tensor) -> Tensor:
+        # fp16 callers (`model.half()`, reference tests/test_model/test_Unet_expert.py:106-115): converted at ingest, computed in fp32 (the
+        # parameters through ops.f32_params), returned in fp16
+        half = x.dtype == torch.float16
+        if half:
+            x = ops.cast(x.contiguous(), torch.float32)
         te = ops.cast(time_emb, torch.float32)
         tx = None if text_emb is None else ops.cast(text_emb, torch.float32)
-        return ops.from_nhwc(unet_expert_bank_forward([self], ops.to_nhwc(x), te, tx, None))
+        y = ops.from_nhwc(unet_expert_bank_forward([self], ops.to_nhwc(x), te, tx, None))
+        return ops.cast(y, torch.float16) if half else y
 
 
 class Vit_block(nn.Module):

@@ -36,15 +36,28 @@ def _storage_view(t: Tensor) -> Tensor:
 
 def normalize(x: Tensor, dim: Optional[list] = None, eps: float = 1e-4) -> Tensor:
     """x / (eps + ||x||_2(dim) * sqrt(n_norm / n_x))  (reference model_internals.py:8-30).
-    Supported reductions: all-but-first (default) and the channel dim of a 4-D tensor."""
+
+    The kernel's eps is 1e-4 (every reference call site); another eps > 0 uses x / (eps + s |x|) == (x k) / (1e-4 + s |x k|) with
+    k = 1e-4 / eps.  Reductions other than all-but-first / the channel dim of a 4-D tensor move the reduced dims to the end first."""
+    if not eps > 0:
+        raise NotImplementedError("normalize: eps must be positive")
     if eps != 1e-4:
-        raise NotImplementedError("normalize: eps is fixed to 1e-4 in the HIP kernels")
+        x = ops.axpby(x.contiguous(), None, 1e-4 / float(eps), 0.0)
     if dim is None or sorted(d % x.ndim for d in dim) == list(range(1, x.ndim)):
         flat = x.contiguous().reshape(x.shape[0], -1)
         return ops.pixel_norm(flat).reshape(x.shape)
     if x.ndim == 4 and [d % 4 for d in dim] == [1]:
         return ops.from_nhwc(ops.pixel_norm(ops.to_nhwc(x)))
-    raise NotImplementedError(f"normalize: unsupported dim={dim} for a {x.ndim}-D tensor")
+    red = sorted({d % x.ndim for d in dim})
+    keep = [d for d in range(x.ndim) if d not in red]
+    perm = keep + red
+    xp = x.permute(perm).contiguous()
+    R = 1
+    for d in red:
+        R *= x.shape[d]
+    out = ops.pixel_norm(xp.reshape(-1, R)).reshape(xp.shape)
+    inv = [perm.index(d) for d in range(x.ndim)]
+    return out.permute(inv)
 
 
 def mp_silu(x: Tensor) -> Tensor:
@@ -67,20 +80,23 @@ def mp_cat(a: Tensor, b: Tensor, dim: int = 1, t: float = 0.5) -> Tensor:
     """Magnitude-preserving concat (reference model_internals.py:69-92); channel dim of NCHW / last dim otherwise."""
     if a.ndim == 4 and dim % 4 == 1:
         return ops.from_nhwc(ops.mp_cat(ops.to_nhwc(a), ops.to_nhwc(b), t))
-    if dim % a.ndim == a.ndim - 1:
+    d = dim % a.ndim
+    if d == a.ndim - 1:
         return ops.mp_cat(a, b, t)
-    raise NotImplementedError("mp_cat: only the channel dim of NCHW tensors or the last dim is supported")
+    # any other dim: concatenate along the last dim of the transposed tensors (the kernel's layout), transpose back
+    return ops.mp_cat(a.transpose(d, -1).contiguous(), b.transpose(d, -1).contiguous(), t).transpose(d, -1)
 
 
 def resample(x: Tensor, f=(1, 1), mode: Optional[str] = "keep") -> Tensor:
-    """Box-filter resampling (reference model_internals.py:95-127) for the default f=[1,1]."""
+    """Separable-filter resampling (reference model_internals.py:95-127): f = [1, 1] is a 2x2 mean / nearest x2; any other even-length
+    filter (up to 8 taps) runs on the generic FIR kernels."""
     if mode == "keep":
         return x
-    if list(f) != [1, 1]:
-        raise NotImplementedError("resample: only the default f=[1,1] filter is implemented")
+    if torch.is_tensor(f):
+        f = f.detach().cpu().tolist()
     if mode not in ("down", "up"):
         raise ValueError(f"Invalid mode: {mode}")
-    return ops.from_nhwc(ops.resample(ops.to_nhwc(x), mode))
+    return ops.from_nhwc(ops.resample(ops.to_nhwc(x), mode, f=list(f)))
 
 
 class MP_Fourier(nn.Module):
@@ -97,12 +113,29 @@ class MP_Fourier(nn.Module):
 
 
 class Pos_encoding(nn.Module):
-    """Present for import compatibility only: unused by every model in the reference
-    (model_internals.py:177 "not used right now") and therefore outside the accelerated path."""
+    """Sinusoidal timestep features -> Linear -> SiLU -> Linear (reference model_internals.py:178-206; unused by the reference's models,
+    kept for its callers and tests).  Same parameters / buffer (`mlp.0`, `mlp.2`, `freq`); the features come from the Fourier kernel
+    ([cos(t f), sin(t f)] = cos(t [f, f] + [0, -pi/2])), the two plain linears from the conv kernel with un-normalised weights."""
 
     def __init__(self, emb_dim: Optional[int] = 512, freq_emb_dim: Optional[int] = 256, max_period: Optional[int] = 10000):
         super().__init__()
-        raise NotImplementedError("Pos_encoding is not on the HDMOEM hot path and is not provided by this build")
+        assert freq_emb_dim % 2 == 0
+        self.half_dim = freq_emb_dim // 2
+        self.max_period = max_period
+        self.mlp = nn.Sequential(nn.Linear(in_features=freq_emb_dim, out_features=emb_dim), nn.SiLU(),
+                                 nn.Linear(in_features=emb_dim, out_features=emb_dim))
+        expo = -1 * np.log(self.max_period) * torch.arange(start=0, end=self.half_dim, dtype=torch.float32) / self.half_dim
+        self.register_buffer("freq", torch.exp(expo))
+
+    def forward(self, time_vec: Tensor) -> Tensor:
+        if time_vec.ndim > 1:
+            time_vec = time_vec.flatten()
+        f2 = torch.cat([self.freq, self.freq])
+        ph = torch.cat([torch.zeros_like(self.freq), torch.full_like(self.freq, -0.5 * math.pi)])
+        emb = ops.axpby(ops.fourier(time_vec, f2, ph), None, 1.0 / math.sqrt(2.0), 0.0)        # the kernel returns sqrt(2) cos(.)
+        h = ops.bias_add(ops.mp_conv(emb, self.mlp[0].weight, 1.0, normalize=False), self.mlp[0].bias)
+        h = ops.axpby(ops.mp_silu(h), None, 0.596, 0.0)                                         # plain SiLU = 0.596 * mp_silu
+        return ops.bias_add(ops.mp_conv(h, self.mlp[2].weight, 1.0, normalize=False), self.mlp[2].bias)
 
 
 class MP_Conv(nn.Module):
@@ -122,7 +155,9 @@ class MP_Conv(nn.Module):
     def _fwd(self, x: Tensor, gain=1.0, **kw) -> Tensor:
         """channel-last in / out; extra kwargs (res/alpha/beta/ones) are forwarded to ops.mp_conv."""
         if self.stride != 1:
-            raise NotImplementedError("MP_Conv with stride > 1 is unused by the reference models and not implemented")
+            if kw or x.ndim != 4 or torch.is_tensor(gain):
+                raise NotImplementedError("MP_Conv(stride > 1): plain 4-D forward only (no reference model uses a strided MP_Conv)")
+            return ops.mp_conv_strided(x, self.weights, gain, self.stride, training=self.training)
         return ops.mp_conv(x, self.weights, gain, training=self.training, **kw)
 
     def forward(self, x: Tensor, gain: float = 1.0) -> Tensor:

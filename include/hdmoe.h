@@ -29,6 +29,7 @@ extern "C" {
 #define HDMOE_ELAUNCH (-3)
 #define HDMOE_F32 0
 #define HDMOE_BF16 1
+#define HDMOE_F16 3  /* hdmoe_cast only: fp16 tensors at the module boundary (`.half()` callers) are converted at ingest / egress */
 #define HDMOE_F32S 2 /* fp32 activations computed as split bf16 (hi + lo, three MFMAs per product): weight images = bf16 [hi | lo] planes */
 #define HDMOE_MAX_GROUPS 8
 #endif
@@ -123,6 +124,11 @@ int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int 
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, HS stream);                     /* a*x + c */
 int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, HS stream);
 int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
+/* Separable even-length FIR resampling, channel-last (resample(x, f, mode) for f other than [1, 1]; reference models/model_internals.py:95-127):
+ * up == 0: stride-2 depthwise correlation with outer(k, k) and padding `pad` (F.conv2d there); up == 1: its transpose (F.conv_transpose2d).
+ * taps: L <= 8 host floats.  Each direction is the other's backward. */
+int hdmoe_fir_resample(void* y, const void* x, const float* taps, int L, int pad, float scale, int up, int N, int H, int W, int Ho, int Wo, int C,
+                       int dtype, HS stream);
 int hdmoe_mp_silu_fwd(void* out, const void* x, long n, int dtype, HS stream);
 int hdmoe_mp_silu_bwd(void* dx, const void* dy, const void* x, long n, int dtype, HS stream);
 /* fused decoder-block entry (model_components.py:232-253): the block input feeds mp_silu AND the skip / residual path */
@@ -269,8 +275,12 @@ int hdmoe_router_head_bwd(float* dlogits, const float* dsparse, const float* dpr
                           HS stream);
 int hdmoe_dispatch_plan(int* perm, int* row_expert, float* row_w, int* inv, int* seg, const float* sparse, int B, int E,
                         int kcap, HS stream);
-/* counts[e] = seg[e+1] - seg[e] as float: rows routed to expert e this step (read by hdmoe_mt_adamw's `use` flags) */
+/* counts[e] += seg[e+1] - seg[e] as float: rows routed to expert e since the last optimizer step (read by hdmoe_mt_adamw's `use` flags;
+ * cleared by the caller behind the update) */
 int hdmoe_seg_counts(float* counts, const int* seg, int E, HS stream);
+/* counts[e] += rows of `sparse` (B, E) with a weight > 0 in column e: the same bookkeeping on the path that evaluates every expert on
+ * the whole batch (no dispatch plan); reference models/model_config1.py:26-29. */
+int hdmoe_route_counts(float* counts, const float* sparse, int B, int E, HS stream);
 int hdmoe_gather_rows(void* dst, const void* src, const int* perm, long R, long L, int dtype, HS stream);
 int hdmoe_combine_rows_fwd(void* out, const void* ys, const int* inv, const float* row_w, long B, int kcap, long L,
                            int dtype, HS stream);

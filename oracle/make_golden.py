@@ -409,10 +409,76 @@ def logger_fixture():
     print("logger:", {k: len(v) for k, v in files.items()})
 
 
+def round4_pins():
+    """Boundary cases SURVEY.md section 8(c) lists that had no fixture before round 4: a non-square 64 x 128 Unet_expert and the
+    `.half()` forward (reference tests/test_model/test_Unet_expert.py:95-115), Pos_encoding (tests/test_model/test_encoding_scheme.py),
+    and the public-API argument values the shipped configs never use (normalize eps / dims, mp_cat dims, resample filters, MP_Conv stride).
+    Written to its own file so the earlier fixtures stay byte-identical."""
+    gen = torch.Generator().manual_seed(404)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    cases = {}
+    torch.manual_seed(41)
+    ue = mc.Unet_expert(img_resolution=64, img_channels=4, time_emb_dim=6, text_emb_dim=5, channel_mult=[1, 2],
+                        model_channels=8, channel_mult_emb=2, num_blocks=1, kernel_size=(3, 3)).eval()
+    wake_zero_inits(ue, gen)
+    xx, te, tx = rn(1, 4, 64, 128).requires_grad_(True), rn(1, 6), rn(1, 5)
+    out = ue(xx, te, tx)
+    go = rn(*out.shape)
+    out.backward(go)
+    cases["unet_expert_64x128"] = dict(state=sd(ue), x=xx.detach().clone(), te=te, text=tx, out=out.detach().clone(), grad_out=go,
+                                       x_grad=xx.grad.clone(),
+                                       param_grads=grads_of(ue, ["out_gain", "encoders.64x64_conv.weights", "decoders.32x32_in0.conv_res1.weights"]))
+    torch.manual_seed(43)
+    uh = mc.Unet_expert(img_resolution=8, img_channels=4, time_emb_dim=6, text_emb_dim=5, channel_mult=[1, 2],
+                        model_channels=8, channel_mult_emb=2, num_blocks=1, kernel_size=(3, 3)).eval()
+    wake_zero_inits(uh, gen)
+    st32 = sd(uh)
+    xh, th, txh = rn(2, 4, 8, 8), rn(2, 6), rn(2, 5)
+    out32 = uh(xh, th, txh).detach().clone()
+    uh = uh.half()
+    try:
+        outh = uh(xh.half(), th.half(), txh.half()).detach().clone()
+    except Exception as e:                                      # CPU half kernels missing in this torch build: dtype / shape pin only
+        print("half forward on CPU failed:", type(e).__name__, e)
+        outh = None
+    cases["unet_expert_half"] = dict(state=st32, x=xh, te=th, text=txh, out_fp32=out32, out_half=outh)
+    torch.manual_seed(47)
+    pe = mi.Pos_encoding(emb_dim=16, freq_emb_dim=8, max_period=10000).eval()
+    t1 = (3.0 * rn(5)).requires_grad_(True)
+    o1 = pe(t1)
+    g1 = rn(*o1.shape)
+    o1.backward(g1)
+    cases["pos_encoding"] = dict(state=sd(pe), emb_dim=16, freq_emb_dim=8, t=t1.detach().clone(), out=o1.detach().clone(), grad_out=g1,
+                                 param_grads=grads_of(pe, [n for n, _ in pe.named_parameters()]),
+                                 out_2d=pe(t1.detach().reshape(5, 1)).detach().clone())
+    x = rn(3, 6, 5, 4)
+    cases["normalize_eps"] = dict(x=x, eps=1e-2, out=mi.normalize(x, eps=1e-2))
+    cases["normalize_dim23"] = dict(x=x, dim=[2, 3], out=mi.normalize(x, dim=[2, 3]))
+    cases["normalize_dim1_eps"] = dict(x=x, dim=[1], eps=3e-3, out=mi.normalize(x, dim=[1], eps=3e-3))
+    a, b0, b2 = rn(2, 4, 3, 5), rn(3, 4, 3, 5), rn(2, 4, 6, 5)
+    cases["mp_cat_dim0"] = dict(a=a, b=b0, dim=0, t=0.3, out=mi.mp_cat(a, b0, dim=0, t=0.3))
+    cases["mp_cat_dim2"] = dict(a=a, b=b2, dim=2, t=0.6, out=mi.mp_cat(a, b2, dim=2, t=0.6))
+    y = rn(2, 3, 8, 6).requires_grad_(True)
+    for mode in ("down", "up"):
+        o = mi.resample(y, f=[1, 3, 3, 1], mode=mode)
+        g = rn(*o.shape)
+        (gy,) = torch.autograd.grad(o, y, g)
+        cases[f"resample_f1331_{mode}"] = dict(x=y.detach().clone(), f=[1, 3, 3, 1], out=o.detach().clone(), grad_out=g, x_grad=gy.clone())
+    torch.manual_seed(53)
+    cs = mi.MP_Conv(5, 8, (3, 3), stride=2).eval()
+    xs = rn(2, 5, 9, 8)
+    cases["mp_conv_stride2"] = dict(state=sd(cs), x=xs, out=cs(xs, gain=1.1).detach().clone(), gain=1.1)
+    torch.save(cases, os.path.join(OUT, "round4.pt"))
+    print("round4:", list(cases.keys()), "half:", None if cases["unet_expert_half"]["out_half"] is None else cases["unet_expert_half"]["out_half"].dtype)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if "--round4-only" in sys.argv:
+        round4_pins()
+        sys.exit(0)
     if "--logger-only" in sys.argv:
         logger_fixture()
         sys.exit(0)
@@ -428,6 +494,7 @@ if __name__ == "__main__":
         full_model(2)
         logger_fixture()
         sampler_fixture()
+        round4_pins()
     wide_model(1, 8, 41)                                  # BASELINE configs[0]: 3-channel, top-1, B = 8
     wide_model(2, 4, 21)
     wide_model(3, 4, 32)
