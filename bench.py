@@ -99,6 +99,47 @@ def pmc_traffic(kernel_name):
     return round(tot / n) if n else None
 
 
+def replay_profile(kernel_name):
+    """(average duration in us of `kernel_name` INSIDE the replayed step, launches per step of the whole step, summed kernel ms per step, file)
+    from the newest committed rocprofv3 kernel trace summary (profiles/rNN_kernel_hist.txt, tools/kernel_hist.py over `rocprofv3 --kernel-trace
+    --stats -- python3 bench.py ...`).  The roofline's own clock is HIP events around eager launches; this is the same kernel's duration while
+    the four streams of the replayed step share the chip.  (None, ...) when no trace is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_hist.txt")))
+    if not files:
+        return None, None, None, None
+    txt = open(files[-1]).read().split("--- by launch count")[0].splitlines()
+    launches = summed = None
+    m = re.match(r"\s*(\d+) launches/step, ([\d.]+) ms summed", txt[0]) if txt else None
+    if m:
+        launches, summed = int(m.group(1)), float(m.group(2))
+    base = kernel_name.split("<")[0].split(" ")[0]
+    n = t = 0.0
+    for ln in txt[1:]:
+        mm = re.match(r"\s*([\d.]+) x\s+([\d.]+) us =\s+([\d.]+) ms\s+(\S+)", ln)
+        if mm and mm.group(4).startswith(base) or (mm and base == "bwd6_kernel" and mm.group(4).startswith("bwd7_kernel")):
+            n += float(mm.group(1)); t += float(mm.group(1)) * float(mm.group(2))
+    return (round(t / n, 2) if n else None), launches, summed, os.path.join("profiles", os.path.basename(files[-1]))
+
+
+# Algorithmic forward MFLOP per sample at R = 32, C = 32 (SURVEY.md section 8(d), torch.utils.flop_counter on the reference modules)
+FWD_MFLOP = {"router": 490.8, "unet": {3: 802.1, 5: 2178.9, 7: 4244.0}, "vit": {4: 13.3, 8: 6.2, 16: 4.8, 2: 65.2}, "xattn": 142.6, "text": 21.9, "misc": 9.0}
+
+
+def whole_step_flops(kw, B):
+    """fwd + bwd FLOPs of one B-sample step (3 x forward), nominal even routing over the experts; None outside the table's shapes."""
+    if kw["IN_img_resolution"] != 32 or kw["internal_channels"] != 32:
+        return None
+    try:
+        fu = sum(FWD_MFLOP["unet"][k[0]] for k in kw["Unet_kernel_sizes"]) / len(kw["Unet_kernel_sizes"])
+        fv = sum(FWD_MFLOP["vit"][p] for p in kw["VIT_patch_sizes"]) / len(kw["VIT_patch_sizes"])
+    except KeyError:
+        return None
+    per_sample = 2 * FWD_MFLOP["router"] + kw["top_k"] * (fu + fv) + FWD_MFLOP["xattn"] + FWD_MFLOP["text"] + FWD_MFLOP["misc"]
+    return 3.0 * per_sample * 1e6 * B
+
+
 def roofline_leg(step_fn, n_steps):
     """Time every conv-family launch of a few extra steps with events on the launch stream; report the kernel
     instantiation with the largest total time.  achieved = sum(algorithmic FLOPs) / sum(duration)."""
@@ -171,7 +212,7 @@ def roofline_leg(step_fn, n_steps):
                     avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps, ms_per_step=round(a["ms"] / n_steps, 3))
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     # the expert grouped-GEMM kernels (bf16): the north_star's MFMA-utilisation target is about these, whatever kernel dominates
-    bf = {k: v for k, v in agg.items() if v["dtype"] == "bfloat16" and ("conv6_bf16" in k or "wgrad6_kernel" in k or "bwd6_kernel" in k or "blk6" in k)}
+    bf = {k: v for k, v in agg.items() if v["dtype"] == "bfloat16" and ("conv6_bf16" in k or "conv7" in k or "wgrad6_kernel" in k or "bwd6_kernel" in k or "blk6" in k)}
     expert = None
     if bf:
         en, ea = max(bf.items(), key=lambda kv: kv[1]["ms"])
@@ -191,6 +232,7 @@ def roofline_leg(step_fn, n_steps):
     return dict(bound="mfma", kernel=name, dtype=a["dtype"], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                 traffic=tr, traffic_source=getattr(pmc_traffic, "source", None) if tr is not None else None,
                 avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), launches_per_step=a["n"] / n_steps, ms_per_step=round(a["ms"] / n_steps, 3),
+                clock="HIP events around each EAGER launch (launch stream; kernels run one at a time)",
                 method="HIP events around each launch on the launch stream, a spacer launch in front keeps host enqueue gaps out and the event-pair overhead measured on a trivial launch is subtracted; see profiles/", event_overhead_us=round(1e3 * overhead, 2)), table
 
 
@@ -259,7 +301,7 @@ def cpu_baseline(cfg_id, kw, module, seconds=9.0):
     return med, B, cores, len(times)
 
 
-def sampler_leg(device, B=128, N=40):
+def sampler_leg(device, B=128, N=40, chunk=0):
     """BASELINE configs[4] on this GPU's share of the batch (1024 images over 8 GPUs = 128 per GPU): EDM_Sampler, 2nd-order Heun, N = 40
     solver steps = 79 denoiser evaluations, 8 heterogeneous experts top-2, 4x64x64 latents, bf16, eval, the evaluation replayed as a
     hipGraph.  Independent replicas: no collective.  Returns a record for the bench line."""
@@ -279,17 +321,21 @@ def sampler_leg(device, B=128, N=40):
     noise = torch.randn(B, 4, 64, 64, device=device, generator=g)
     text = torch.randn(B, 77, kw["text_emb_dim"], device=device, generator=g)
     smp = EDM_Sampler(model, Guide_net=model, guidance=1.0, num_solve_steps=N, use_graph=True)
+    chunk = chunk or B                                          # B images as B / chunk consecutive sample() calls through the SAME captured graph
     with torch.no_grad():
-        smp.sample(noise=noise, text_emb=text, transition_mean=-1.2, softness=1.2)     # warm-up + capture
+        smp.sample(noise=noise[:chunk], text_emb=text[:chunk], transition_mean=-1.2, softness=1.2)     # warm-up + capture
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = smp.sample(noise=noise, text_emb=text, transition_mean=-1.2, softness=1.2)
+        outs = [smp.sample(noise=noise[i:i + chunk], text_emb=text[i:i + chunk], transition_mean=-1.2, softness=1.2) for i in range(0, B, chunk)]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    ok = bool(torch.isfinite(out).all())
-    return dict(metric="imgs/sec, EDM_Sampler (BASELINE configs[4] per-GPU share)", value=round(B / dt, 2) if ok else None, batch=B, solver_steps=N,
-                denoiser_evals=2 * N - 1, ms_per_eval=round(1e3 * dt / (2 * N - 1), 3), latents="4x64x64", experts="8 heterogeneous (3x3 / 5x5 / 7x7), top-2",
-                dtype="bf16", launch="hipGraph replay of the denoiser evaluation", finite=ok)
+    ok = all(bool(torch.isfinite(o).all()) for o in outs)
+    nev = (2 * N - 1) * (B // chunk)
+    return dict(metric="imgs/sec, EDM_Sampler (BASELINE configs[4]" + (" per-GPU share)" if B == 128 else ", whole batch on ONE GPU)"), value=round(B / dt, 2) if ok else None,
+                batch=B, chunk=chunk, solver_steps=N, denoiser_evals=nev, ms_per_eval=round(1e3 * dt / nev, 3), latents="4x64x64",
+                experts="8 heterogeneous (3x3 / 5x5 / 7x7), top-2", dtype="bf16",
+                launch="hipGraph replay: denoiser evaluation + the Heun update kernels of a solver stage, sigma schedule read on the device" if getattr(smp, "fused_heun", False) else "hipGraph replay of the denoiser evaluation",
+                finite=ok)
 
 
 def main():
@@ -302,6 +348,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true", help="skip the EDM_Sampler leg (BASELINE configs[4] shape, ~4 s)")
+    ap.add_argument("--sampler-batch", type=int, default=0, help="also sample this many images on ONE GPU (BASELINE configs[4]: 1024) as chunks of 128 through one captured graph")
+    ap.add_argument("--no-fp32-trunk-leg", action="store_true", help="skip the second timed leg with the three-product (fp32-equivalent) router-trunk backward")
     ap.add_argument("--dump-kernels", default="", help="write the per-kernel table of the roofline leg to this JSON file")
     ap.add_argument("--single-graph", action="store_true", help="capture the step as ONE hipGraph instead of the seven staged graphs (A/B)")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: synchronize after every step (the host never runs ahead of the GPU)")
@@ -474,6 +522,30 @@ def main():
         inp["um"].copy_(um_save); inp["vm"].copy_(vm_save)
     except Exception as exc:                                  # diagnostic leg only
         print(f"[bench] masked leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+    # third leg: the to-the-letter "fp32 router" configuration -- the router trunks' BACKWARD with the three-product
+    # (fp32-equivalent) split arithmetic as well (default: bf16 operands + fp32 accumulation; a 300-step A/B is in profiles/r03_trunk_bwd_precision.json)
+    ms_fp32_trunk = None
+    if world == 1 and not args.no_fp32_trunk_leg and not args.no_graph and graphed is not None and not args.single_graph and bc["dtype"] == "bf16":
+        prev_flag = ops.TRUNK_BWD_BF16
+        try:
+            ops.TRUNK_BWD_BF16 = False
+            buckets.enabled = False
+            g2 = StagedStep(fwd_bwd, device)
+            buckets.enabled = True
+            for _ in range(3):
+                g2(); buckets.finish()
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            for _ in range(args.steps):
+                g2(); buckets.finish()
+            torch.cuda.synchronize()
+            ms_fp32_trunk = 1e3 * (time.perf_counter() - tm) / args.steps
+            g2 = None
+        except Exception as exc:                              # diagnostic leg only
+            print(f"[bench] fp32-equivalent trunk-backward leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        finally:
+            ops.TRUNK_BWD_BF16 = prev_flag
+            buckets.enabled = True
     roof, table = (None, {})
     cpu = None
     launch_desc = "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)")
@@ -495,6 +567,23 @@ def main():
             roofline_leg.expert = expert_in_step
             if roofline_leg.expert is not None and expert_unfused is not None:
                 roofline_leg.expert["unfused_eager_leg"] = {k: expert_unfused[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "ms_per_step", "all_expert_kxk_kernels") if k in expert_unfused}
+            if roof is not None:
+                # the same kernel's clock inside the replayed step (committed rocprofv3 trace), the whole step against the bf16 MFMA peak,
+                # and how many launches a replayed step is
+                rep_us, launches, summed_ms, src = replay_profile(roof["kernel"])
+                roof["in_replay_avg_us"] = rep_us
+                roof["in_replay_frac"] = round(roof["frac"] * roof["avg_launch_us"] / rep_us, 4) if rep_us else None
+                roof["in_replay_source"] = src
+                wf = whole_step_flops(kw, B)
+                roof["whole_step"] = None if wf is None else dict(flops=wf, achieved=round(wf / (ms * 1e-3) / 1e12, 1), unit="TFLOP/s",
+                                                                  frac=round(wf / (ms * 1e-3) / 1e12 / MFMA_PEAK["bfloat16"], 4),
+                                                                  note="3 x forward FLOPs (SURVEY 8(d) table, nominal even routing) / ms_per_step, against the bf16 MFMA peak")
+                from hdmoe_hip import _lib as hlib
+                hlib.CALL_LOG = []
+                local_step()
+                torch.cuda.synchronize()
+                n_calls, hlib.CALL_LOG = len(hlib.CALL_LOG), None
+                roof["launches_per_step"] = dict(profiled=launches, summed_kernel_ms_per_step=summed_ms, source=src, c_abi_calls_per_eager_step=n_calls)
             if args.dump_kernels:
                 with open(args.dump_kernels, "w") as f:
                     json.dump({"in_step_launches": table, "unfused_launches": table_u}, f, indent=1)
@@ -504,6 +593,8 @@ def main():
                 gc.collect()
                 torch.cuda.empty_cache()
                 sampler_rec = sampler_leg(device)
+                if args.sampler_batch:
+                    sampler_rec["whole_batch_one_gpu"] = sampler_leg(device, B=args.sampler_batch, chunk=128)
             except Exception as exc:                          # a reported extra, never a reason to lose the headline line
                 print(f"[bench] sampler leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
                 sampler_rec = None
@@ -524,6 +615,7 @@ def main():
             # (an implausible loss means the step computed garbage: no headline number then, and a non-zero exit code below)
             "metric": "denoise-steps/sec (fwd+bwd) on 4x32x32 latents", "value": round(world * 1e3 / ms, 4) if loss_ok else None,
             "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_fp32_equiv_trunk_bwd": None if ms_fp32_trunk is None else round(ms_fp32_trunk, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bc["dtype"] == "bf16" else "f32",
             "data": "synthetic", "samples_per_sec": round(world * B * 1e3 / ms, 1),
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: model_config{bc['module']} preconditioned_HDMOEM, "

@@ -1,9 +1,11 @@
 """Heun 2nd-order EDM sampler -- drop-in for the reference's ``Utils/EDM_sampler.py`` (row N1 of SURVEY.md section 8(f)).
 
 Same constructor / ``denoise`` / ``sample`` signatures and semantics (Karras rho-schedule, optional churn, CFG lerp).  The
-2N-1 model evaluations run through the HIP path; the per-step latent updates are fused axpby launches (no torch arithmetic on
-the latents), and the denoiser call is sync-free (device-side dispatch plan, no ``mask.any()``), so with ``use_graph=True``
-one ``denoise`` evaluation is captured in a hipGraph on first use and replayed for all 2N-1 solver stages.
+2N-1 model evaluations run through the HIP path; the per-step latent updates are fused launches (no torch arithmetic on the latents), and
+the denoiser call is sync-free (device-side dispatch plan, no ``mask.any()``).  With ``use_graph=True`` (and no churn) a WHOLE Heun stage --
+both evaluations, the Euler step and the 2nd-order correction, sigma taken from a device-side copy of the schedule -- is one captured
+hipGraph replayed N - 1 times (plus one for the last, Euler-only stage): no host arithmetic between evaluations.  With churn the
+evaluation alone is captured, as before.
 """
 import numpy as np
 import torch
@@ -31,6 +33,11 @@ class EDM_Sampler:
         self.use_graph = use_graph          # extension over the reference: hipGraph replay of the denoiser evaluation
         self._graph = None
         self._gkey = None
+        # use_graph and no churn, fp32 latents: a whole solver stage (both denoiser evaluations + the fused Euler / Heun-correction kernels,
+        # sigma read from a device-side schedule) is ONE captured graph, replayed N - 1 times, plus one graph for the last (Euler-only) stage
+        self.fused_heun = False
+        self._stage = None
+        self._skey = None
 
     # reference Utils/EDM_sampler.py:35-70
     def denoise(self, x, sigma, text_emb, transition_mean, softness, uncond_text_emb=None):
@@ -78,6 +85,47 @@ class EDM_Sampler:
         self._graph.replay()
         return self._sout.clone()
 
+    # ---- fused solver stage (reference :90-107 without churn) ----------------------------------------------------------
+    def _stage_graphs(self, x, text_emb, transition_mean, softness, uncond_text_emb):
+        key = (tuple(x.shape), tuple(text_emb.shape), float(transition_mean), float(softness), self.num_steps,
+               None if uncond_text_emb is None else tuple(uncond_text_emb.shape))
+        if self._stage is not None and self._skey == key:
+            return self._stage
+        dev = x.device
+        st = dict(x=torch.empty_like(x), xn=torch.empty_like(x), sig=torch.ones((), dtype=torch.float32, device=dev),
+                  t=torch.ones(self.num_steps + 1, dtype=torch.float64, device=dev), idx=torch.zeros(1, dtype=torch.int32, device=dev),
+                  text=text_emb.clone(), unc=None if uncond_text_emb is None else uncond_text_emb.clone())
+        st["x"].copy_(x)
+        n = x.numel()
+
+        def stage(last: bool):
+            ops.call("hdmoe_sched_pick", st["sig"], st["t"], st["idx"], 0)
+            den = self.denoise(st["x"], st["sig"], st["text"], transition_mean, softness, st["unc"])
+            if last:
+                ops.call("hdmoe_heun_euler", st["x"], st["x"], den, st["t"], st["idx"], n)
+            else:
+                ops.call("hdmoe_heun_euler", st["xn"], st["x"], den, st["t"], st["idx"], n)
+                ops.call("hdmoe_sched_pick", st["sig"], st["t"], st["idx"], 1)
+                den2 = self.denoise(st["xn"], st["sig"], st["text"], transition_mean, softness, st["unc"])
+                ops.call("hdmoe_heun_correct", st["x"], st["x"], den, st["xn"], den2, st["t"], st["idx"], n)
+            ops.call("hdmoe_idx_advance", st["idx"])
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # warm-up: registers the weight bank, sizes the allocator pool
+            for _ in range(2):
+                st["idx"].zero_()
+                stage(False)
+        torch.cuda.current_stream().wait_stream(side)
+        st["g_heun"], st["g_last"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        st["idx"].zero_()
+        with torch.cuda.graph(st["g_heun"]):
+            stage(False)
+        with torch.cuda.graph(st["g_last"], pool=st["g_heun"].pool()):
+            stage(True)
+        self._stage, self._skey = st, key
+        return st
+
     def _eval(self, x, t, text_emb, transition_mean, softness, uncond_text_emb):
         if self.use_graph:
             return self._denoise_graphed(x, t, text_emb, transition_mean, softness, uncond_text_emb)
@@ -104,6 +152,19 @@ class EDM_Sampler:
                     m_._hdmoe_bank.refresh_eval()
         t_steps = self.t_schedule(device)
         x_next = ops.axpby(noise.to(self.dtype), None, float(t_steps[0]), 0.0)
+        self.fused_heun = bool(self.use_graph and self.s_churn <= 0 and self.dtype == torch.float32 and noise.is_cuda and self.num_steps >= 2)
+        if self.fused_heun:
+            st = self._stage_graphs(x_next, text_emb, transition_mean, softness, uncond_text_emb)
+            st["x"].copy_(x_next)
+            st["text"].copy_(text_emb)
+            if st["unc"] is not None:
+                st["unc"].copy_(uncond_text_emb)
+            st["t"].copy_(torch.from_numpy(t_steps))
+            st["idx"].zero_()
+            for _ in range(self.num_steps - 1):
+                st["g_heun"].replay()
+            st["g_last"].replay()
+            return st["x"].clone()
         for i in range(self.num_steps):
             t_cur, t_next = float(t_steps[i]), float(t_steps[i + 1])
             x_cur = x_next

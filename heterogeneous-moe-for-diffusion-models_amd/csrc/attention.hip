@@ -899,9 +899,8 @@ static int attn_force_slow() {                                // (tests: the onl
 }
 
 static void attn_mfma_attrs() {                              // (the dk / dv kernel's two buffers are 64 KB + the constant block)
-  static bool done = false;
-  if (done) return;
-  done = true;
+  static unsigned long long done = 0;
+  if (!hdmoe_first_on_device(done)) return;
   (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_KV_BUF + ATT_CONST + 8 * 32 * 8 * 4);
 }
 
@@ -934,8 +933,8 @@ int attn_bwd_launch(void* dq, void* dk, void* dv, float* dbias, float* delta, co
       const float c = scale * 1.4426950408889634f;
       static const bool merged = !(getenv("HDMOE_ATTN_BWD_MERGED") && atoi(getenv("HDMOE_ATTN_BWD_MERGED")) == 0);
       if (merged && Sq <= ATT_HS) {                           // one evaluation of the probabilities for dq, dk and dv
-        static bool attr = false;
-        if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)attn_bwd_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS); }
+        static unsigned long long attr = 0;
+        if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)attn_bwd_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS); }
         int hg = (int)cdiv(512, B); if (hg > H) hg = H; if (hg < 1) hg = 1;
         const int hpw = (int)cdiv(H, hg);
         hipLaunchKernelGGL(attn_bwd_merged_kernel, dim3(cdiv(H, hpw), B), dim3(64 * MG_WAVES), MG_LDS, st, (bf16*)dq, (bf16*)dk, (bf16*)dv,

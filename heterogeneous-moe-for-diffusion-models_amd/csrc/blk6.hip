@@ -113,9 +113,8 @@ int blk6_plan(const void* x, const void* wa, const void* wb, void* y, const void
 
 template <int MODE>
 int blk6_launch(const B6Plan& plan, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (hdmoe_first_on_device(attr_set)) {
 #define B6_ATTR(W, M, B, L) (void)hipFuncSetAttribute((const void*)blk6_kernel<W, M, B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, L * 1024)
     B6_ATTR(8, 1, 1, 160); B6_ATTR(8, 1, 2, 160); B6_ATTR(8, 2, 1, 160); B6_ATTR(8, 2, 2, 160);
     B6_ATTR(4, 1, 1, 80); B6_ATTR(4, 1, 2, 80); B6_ATTR(4, 2, 1, 80); B6_ATTR(4, 2, 2, 80);

@@ -31,8 +31,8 @@ __global__ __launch_bounds__(512) void bwd6_kernel(C6Args c, W6Args a3, W6Args a
 
 template <int MT, int NT, int TWS, int OT>
 void launch_bwd6(const C6Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd6_kernel<MT, NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  static unsigned long long attr = 0;
+  if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)bwd6_kernel<MT, NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
   const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
   hipLaunchKernelGGL((bwd6_kernel<MT, NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(512) void bwd7_kernel(C7Args c, W6Args a3, W6Args a
 
 template <int CO, int KMASK, int TWS, int OT>
 void launch_bwd7(const C7Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  static unsigned long long attr = 0;
+  if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
   const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
   hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(512) void bwd6s_kernel(C6SArgs c, W6Args a3, int G6
 }
 template <int NT, int TWS, int OT>
 void launch_bwd6s(const C6SPlan& cp, const W6DualPlan& wp, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)bwd6s_kernel<NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  static unsigned long long attr = 0;
+  if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)bwd6s_kernel<NT, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
   const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * wp.c[0].chunks);
   hipLaunchKernelGGL((bwd6s_kernel<NT, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.sa, wp.c[0], (int)cp.G, wp.ibs, wp.obs);

@@ -134,6 +134,16 @@ static inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 
 static inline int hdmoe_launch_status() {
   return hipGetLastError() == hipSuccess ? HDMOE_OK : HDMOE_ELAUNCH;
 }
+// hipFuncSetAttribute applies to the CURRENT device only: "done once" flags are kept per device (bit = device id), so a process that drives
+// several devices raises the dynamic-LDS limit on each of them
+static inline bool hdmoe_first_on_device(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- counter RNG (Philox4x32-10)

@@ -1301,9 +1301,8 @@ int hdmoe_conv_fwd(const void* x, const void* w, void* y, const void* res, float
       while (tg > 1 && (size_t)80 * (halo_cap + tg * maxkw * 32 * NT) > 64 * 1024) --tg;       // prefer <= 64 KB
       const size_t lds3 = (size_t)80 * (halo_cap + tg * maxkw * 32 * NT);
       if (lds3 <= cap && v5ok) {
-        static bool attr_set = false;
-        if (!attr_set) {                                     // opt every instantiation into > 64 KB of dynamic LDS, once
-          attr_set = true;
+        static unsigned long long attr_set = 0;
+        if (hdmoe_first_on_device(attr_set)) {               // opt every instantiation into > 64 KB of dynamic LDS, once per device
 #define CV5_ATTR(TT, NTv, L, H) (void)hipFuncSetAttribute((const void*)conv_fwd5_kernel<TT, NTv, L, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
 #define CV5_ATTR4(TT, NTv) CV5_ATTR(TT, NTv, true, 7); CV5_ATTR(TT, NTv, false, 7); CV5_ATTR(TT, NTv, true, 9); CV5_ATTR(TT, NTv, false, 9)
           CV5_ATTR4(float, 1); CV5_ATTR4(float, 2); CV5_ATTR4(bf16, 1); CV5_ATTR4(bf16, 2);

@@ -122,9 +122,8 @@ int conv6_try_launch(const ConvArgs& c, const ConvFuse* fuse, int dtype, hipStre
   const unsigned G = plan.G;
   const size_t lds = plan.lds;
   const int MT = plan.MT, NT = plan.NT;
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (hdmoe_first_on_device(attr_set)) {
 #define C6_ATTR(M, Nt) (void)hipFuncSetAttribute((const void*)conv6_bf16_kernel<M, Nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     C6_ATTR(1, 1); C6_ATTR(1, 2); C6_ATTR(2, 1); C6_ATTR(2, 2);
 #define C6F_ATTR(M, Nt) (void)hipFuncSetAttribute((const void*)conv6_bf16_kernel<M, Nt, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)

@@ -95,9 +95,8 @@ int conv6_split_try_launch(const ConvArgs& c, long wplane_elems, const ConvFuse*
   static const bool p3 = !(getenv("HDMOE_C6S_P3") && atoi(getenv("HDMOE_C6S_P3")) == 0);   // 0: the three products as separate passes (A/B)
   C6SPlan plan;
   if (conv6s_plan(c, wplane_elems, fuse, plan, p3)) return 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (hdmoe_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv6_split_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv6_split_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -58,8 +58,8 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
 
 template <int CO, int KMASK, bool W16>
 static void conv7_launch_t(const C7Plan& p, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)conv7_kernel<CO, KMASK, W16>, hipFuncAttributeMaxDynamicSharedMemorySize, C7Lds<W16>::BYTES); }
+  static unsigned long long attr = 0;
+  if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)conv7_kernel<CO, KMASK, W16>, hipFuncAttributeMaxDynamicSharedMemorySize, C7Lds<W16>::BYTES); }
   hipLaunchKernelGGL((conv7_kernel<CO, KMASK, W16>), dim3(p.G), dim3(512), C7Lds<W16>::BYTES, stream, p.a);
 }
 

@@ -44,6 +44,32 @@ __global__ void cast_f2h_kernel(_Float16* out, const float* x, long n) { GRID_ST
 //   down: y[oy][ox] = scale * sum_{i,j} k[i] k[j] x[2 oy - pad + i][2 ox - pad + j]           (F.conv2d, stride 2, padding pad, depthwise)
 //   up:   y[oy][ox] = scale * sum over (iy, i) with 2 iy - pad + i == oy (and likewise in x) of k[i] k[j] x[iy][ix]   (F.conv_transpose2d)
 // each is the other's adjoint, so the same two kernels serve the backward passes (with the other one's scale).
+// ---- EDM sampler, one Heun solver stage on the device (reference Utils/EDM_sampler.py:90-107): the sigma schedule t[0..N] (float64, as the
+// host computes it) and the stage index live in device memory, so a captured hipGraph of a stage replays for every stage without host arithmetic
+__global__ void sched_pick_kernel(float* sigma, const double* t, const int* idx, int off) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *sigma = (float)t[*idx + off];
+}
+__global__ void idx_advance_kernel(int* idx) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *idx += 1;
+}
+// x_next = x_hat + (t_next - t_hat) * (x_hat - denoised) / t_hat
+__global__ void heun_euler_kernel(float* xn, const float* xh, const float* den, const double* t, const int* idx, long n) {
+  const int i = *idx;
+  const double th = t[i], h = t[i + 1] - th;
+  const float a = (float)(1.0 + h / th), b = (float)(-h / th);
+  GRID_STRIDE(e, n) xn[e] = a * xh[e] + b * den[e];
+}
+// x_out = x_hat + h * (0.5 * (x_hat - denoised) / t_hat + 0.5 * (x_next - denoised') / t_next)
+__global__ void heun_correct_kernel(float* out, const float* xh, const float* den, const float* xn, const float* den2, const double* t, const int* idx, long n) {
+  const int i = *idx;
+  const double th = t[i], tn = t[i + 1], h = tn - th;
+  const float a1 = (float)(1.0 + 0.5 * h / th), b1 = (float)(-0.5 * h / th), a2 = (float)(0.5 * h / tn), b2 = (float)(-0.5 * h / tn);
+  GRID_STRIDE(e, n) {
+    const float u = a1 * xh[e] + b1 * den[e];
+    const float v = a2 * xn[e] + b2 * den2[e];
+    out[e] = u + v;
+  }
+}
 struct FirTaps { float k[8]; };
 template <typename T>
 __global__ void fir_down_kernel(T* y, const T* x, FirTaps f, int L, int pad, float scale, int H, int W, int Ho, int Wo, int C, long total) {
@@ -954,6 +980,28 @@ extern "C" {
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, hipStream_t stream) {
   DT_SWITCH(dtype, if (n % VT<T>::W == 0 && al16(out) && al16(x) && al16(y)) L1D(axpby_vec_kernel<T>, n / VT<T>::W, (T*)out, (const T*)x, (const T*)y, a, b, n / VT<T>::W);
                    else L1D(axpby_kernel<T>, n, (T*)out, (const T*)x, (const T*)y, a, b, n))
+}
+/* EDM sampler stage pieces (fp32 latents; t: device float64 schedule of N + 1 values, idx: device stage index) */
+int hdmoe_sched_pick(float* sigma, const double* t, const int* idx, int off, hipStream_t stream) {
+  if (!sigma || !t || !idx) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(sched_pick_kernel, dim3(1), dim3(64), 0, stream, sigma, t, idx, off);
+  return hdmoe_launch_status();
+}
+int hdmoe_idx_advance(int* idx, hipStream_t stream) {
+  if (!idx) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(idx_advance_kernel, dim3(1), dim3(64), 0, stream, idx);
+  return hdmoe_launch_status();
+}
+int hdmoe_heun_euler(float* xn, const float* xh, const float* den, const double* t, const int* idx, long n, hipStream_t stream) {
+  if (!xn || !xh || !den || !t || !idx) return HDMOE_EINVAL;
+  L1D(heun_euler_kernel, n, xn, xh, den, t, idx, n);
+  return hdmoe_launch_status();
+}
+int hdmoe_heun_correct(float* out, const float* xh, const float* den, const float* xn, const float* den2, const double* t, const int* idx, long n,
+                       hipStream_t stream) {
+  if (!out || !xh || !den || !xn || !den2 || !t || !idx) return HDMOE_EINVAL;
+  L1D(heun_correct_kernel, n, out, xh, den, xn, den2, t, idx, n);
+  return hdmoe_launch_status();
 }
 int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int n, long nelem, int dtype, hipStream_t stream) {
   if (!out || !srcs || n < 1 || n > 16) return HDMOE_EINVAL;

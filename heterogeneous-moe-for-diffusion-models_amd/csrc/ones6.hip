@@ -104,9 +104,8 @@ int launch_conv6_pitched(const ConvArgs& c, int rowpitch, int tapstride, long wi
   const long wbytes = ((long)(c.ngroups - 1) * c.wstride + wimage_elems) * 2;
   if (wbytes >= (1l << 31)) return 1;
   a.wbytes = (int)wbytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
+  static unsigned long long attr_set = 0;
+  if (hdmoe_first_on_device(attr_set)) {
 #define C6O_ATTR(M, Nt) (void)hipFuncSetAttribute((const void*)conv6_ones_kernel<M, Nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     C6O_ATTR(1, 1); C6O_ATTR(1, 2); C6O_ATTR(2, 1); C6O_ATTR(2, 2);
   }

@@ -133,8 +133,8 @@ template <int KS, int TWS, int OT, bool SPLIT>
 void launch_w6(const W6Args& a, int ibs, int obs, hipStream_t stream) {
   constexpr int TW = 1 << TWS, TH = 256 >> TWS, HP16 = ((TW + KS - 1) * (TH + KS - 1) + 15) / 16;
   const size_t lds = 2 * (size_t)(HP16 * 1024 + 16 * OT * 1024);     // two DMA buffers, or (SPLIT) a hi and a lo plane
-  static bool attr = false;
-  if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)wgrad6_kernel<KS, TWS, OT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  static unsigned long long attr = 0;
+  if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)wgrad6_kernel<KS, TWS, OT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   hipLaunchKernelGGL((wgrad6_kernel<KS, TWS, OT, SPLIT>), dim3(ibs, obs, a.chunks), dim3(512), lds, stream, a);
 }
 
@@ -281,8 +281,8 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
       const dim3 grid(dp.ibs, dp.obs, dp.c[0].chunks + dp.c[1].chunks);
 #define W6_DUAL(T, O)                                                                                                              \
       do {                                                                                                                         \
-        static bool attr_ = false;                                                                                                 \
-        if (!attr_) { attr_ = true; (void)hipFuncSetAttribute((const void*)wgrad6_dual_kernel<T, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+        static unsigned long long attr_ = 0;                                                                                                 \
+        if (hdmoe_first_on_device(attr_)) { (void)hipFuncSetAttribute((const void*)wgrad6_dual_kernel<T, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
         hipLaunchKernelGGL((wgrad6_dual_kernel<T, O>), grid, dim3(512), dp.lds, stream, dp.c[0], dp.c[1]);                         \
       } while (0)
       if (TWS == 5) { if (OT == 2) W6_DUAL(5, 2); else W6_DUAL(5, 1); } else { if (OT == 2) W6_DUAL(4, 2); else W6_DUAL(4, 1); }

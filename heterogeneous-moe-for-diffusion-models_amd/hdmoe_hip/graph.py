@@ -182,6 +182,15 @@ def backward(loss):
         loss.backward()
 
 
+# Timing experiments only (tools/): sections listed in HDMOE_SKIP_STAGE are dropped from the replay -- the step's results
+# are then WRONG.  Read once at import; a left-over setting is announced loudly instead of silently corrupting a training run.
+SKIP_STAGES = tuple(s_ for s_ in __import__("os").environ.get("HDMOE_SKIP_STAGE", "").split(",") if s_)
+if SKIP_STAGES:
+    import warnings as _warnings
+    _warnings.warn(f"hdmoe_hip.graph: HDMOE_SKIP_STAGE={','.join(SKIP_STAGES)} drops these sections from every StagedStep replay -- gradients and "
+                   "loss are WRONG; this switch is for timing experiments only", RuntimeWarning)
+
+
 class StagedStep:
     """Drop-in for GraphedStep when ``step_fn`` runs the banked HDMOEM path and calls ``graph.backward(loss)``."""
 
@@ -243,7 +252,7 @@ class StagedStep:
         cur = torch.cuda.current_stream(self.device)
         ev = self._events = {} if self.timing else None
 
-        skip = __import__("os").environ.get("HDMOE_SKIP_STAGE", "").split(",")   # (timing experiments only: the step's results are wrong)
+        skip = SKIP_STAGES
 
         def run(name, stream):
             if name in skip:

@@ -309,20 +309,36 @@ class _W6Arena:
         self.buf = torch.empty(int(_os.environ.get("HDMOE_W6_ARENA_MB", "1024")) << 18, dtype=torch.float32, device=device)
         self.off = 0
         self.want = 0                                        # floats the current step would have needed
+        self.captured = False                                # a hipGraph capture handed out slices of the CURRENT buffer
+        self._old = []                                       # outgrown buffers that a captured graph may still point into
 
     def take(self, nfloats):
         self.want = (self.want + 63) // 64 * 64 + nfloats    # advances whether or not the slice fits: the next rewind grows to it
         start = (self.off + 63) // 64 * 64
         if start + nfloats > self.buf.numel():
+            if torch.cuda.is_current_stream_capturing():
+                # the captured step would bake the slower non-deferred path in: say how to avoid it instead of degrading silently
+                import warnings
+                warnings.warn(f"hdmoe_hip: the deferred weight-gradient arena ({self.buf.numel() * 4 >> 20} MB) is too small for this step and cannot "
+                              f"grow inside a hipGraph capture; run one eager step before capturing or set HDMOE_W6_ARENA_MB >= "
+                              f"{(self.want * 5 >> 20) + 1}", RuntimeWarning, stacklevel=3)
             return None
         self.off = start + nfloats
+        if torch.cuda.is_current_stream_capturing():
+            self.captured = True
         return self.buf[start:start + nfloats]
 
     def rewind(self):
         if self.want > self.buf.numel() and not torch.cuda.is_current_stream_capturing():
-            self._old = getattr(self, "_old", []) + [self.buf]     # (a captured graph may still point into the old buffer: keep it alive)
+            if self.captured:                                # only a buffer some captured graph points into has to stay alive
+                self._old.append(self.buf)
             self.buf = torch.empty(int(self.want * 1.25) // 64 * 64 + 64, dtype=torch.float32, device=self.device)
+            self.captured = False
         self.off = self.want = 0
+
+    def release_old(self):
+        """Drop the outgrown buffers (call once every graph captured before the last growth has been destroyed)."""
+        self._old.clear()
 
 
 _w6_arenas = {}

@@ -123,6 +123,13 @@ int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long 
 int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int n, long nelem, int dtype, HS stream);   /* sum_k src_scale[k] * srcs[k], n <= 16 tensors (16-byte aligned), src_scale = host array or NULL (all 1): fan-out backward */
 int hdmoe_affine(void* out, const void* x, float a, float c, long n, int dtype, HS stream);                     /* a*x + c */
 int hdmoe_mul(void* out, const void* x, const void* y, long n, int dtype, HS stream);
+/* One Heun stage of the EDM sampler with the sigma schedule on the device (reference Utils/EDM_sampler.py:90-107): t = float64 [N + 1] device
+ * array, idx = device int32 stage counter.  sched_pick: *sigma = t[*idx + off];  heun_euler: x_next = x_hat + (t[i+1] - t[i]) (x_hat - den) / t[i];
+ * heun_correct: out = x_hat + h (0.5 (x_hat - den) / t[i] + 0.5 (x_next - den2) / t[i+1]);  idx_advance: *idx += 1.  fp32 latents of n elements. */
+int hdmoe_sched_pick(float* sigma, const double* t, const int* idx, int off, HS stream);
+int hdmoe_idx_advance(int* idx, HS stream);
+int hdmoe_heun_euler(float* xn, const float* xh, const float* den, const double* t, const int* idx, long n, HS stream);
+int hdmoe_heun_correct(float* out, const float* xh, const float* den, const float* xn, const float* den2, const double* t, const int* idx, long n, HS stream);
 int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
 /* Separable even-length FIR resampling, channel-last (resample(x, f, mode) for f other than [1, 1]; reference models/model_internals.py:95-127):
  * up == 0: stride-2 depthwise correlation with outer(k, k) and padding `pad` (F.conv2d there); up == 1: its transpose (F.conv_transpose2d).

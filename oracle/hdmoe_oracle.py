@@ -83,19 +83,22 @@ def mp_cat(a: Tensor, b: Tensor, dim: int = 1, t: float = 0.5) -> Tensor:
     return torch.cat([wa * a, wb * b], dim=dim)
 
 
-def resample(x: Tensor, mode: str = "keep") -> Tensor:
-    """f=[1,1] resampling (model_internals.py:95-127): 'down' is the depthwise
-    stride-2 conv with 0.25 taps (== 2x2 mean pool); 'up' is the depthwise
-    transposed conv with unit taps (== nearest x2)."""
+def resample(x: Tensor, mode: str = "keep", f: Sequence[float] = (1.0, 1.0)) -> Tensor:
+    """Separable even-length FIR resampling (model_internals.py:95-127).  f=[1,1]:
+    'down' is the depthwise stride-2 conv with 0.25 taps (== 2x2 mean pool); 'up'
+    the depthwise transposed conv with unit taps (== nearest x2)."""
     if mode == "keep":
         return x
+    f1 = torch.tensor(list(f), dtype=torch.float32)
+    assert f1.ndim == 1 and f1.shape[0] % 2 == 0
+    pad = (f1.shape[0] - 1) // 2
+    f1 = f1 / f1.sum()
     c = x.shape[1]
+    k = torch.outer(f1, f1)[None, None].to(x.dtype).repeat(c, 1, 1, 1)
     if mode == "down":
-        k = torch.full((c, 1, 2, 2), 0.25, dtype=x.dtype)
-        return F.conv2d(x, k, stride=2, groups=c)
+        return F.conv2d(x, k, stride=2, groups=c, padding=pad)
     if mode == "up":
-        k = torch.ones((c, 1, 2, 2), dtype=x.dtype)
-        return F.conv_transpose2d(x, k, stride=2, groups=c)
+        return F.conv_transpose2d(x, k * 4, stride=2, groups=c, padding=pad)
     raise ValueError(mode)
 
 
@@ -114,18 +117,31 @@ def mp_weight(w: Tensor, gain=1.0) -> Tensor:
     return w * (gain / math.sqrt(w[0].numel()))
 
 
-def mp_conv(x: Tensor, w: Tensor, gain=1.0) -> Tensor:
+def mp_conv(x: Tensor, w: Tensor, gain=1.0, stride: int = 1) -> Tensor:
     """MP_Conv.forward in eval mode (model_internals.py:253-275): linear for
     2-D inputs; stride-1 conv with explicit 'same' padding (left (k-1)//2,
-    right the rest, k = last kernel dim) for 4-D inputs.  No bias."""
+    right the rest, k = last kernel dim) for 4-D inputs; stride > 1: padding
+    k // 2 (:272-275).  No bias."""
     we = mp_weight(w, gain).to(x.dtype)
     if x.ndim == 2:
         return F.linear(x, we)
     assert x.ndim == 4
     k = we.shape[-1]
+    if stride != 1:
+        return F.conv2d(x, we, padding=k // 2, stride=stride)
     lo = (k - 1) // 2
     hi = (k - 1) - lo
     return F.conv2d(F.pad(x, (lo, hi, lo, hi)), we)
+
+
+def pos_encoding(P: "Params", pre: str, time_vec: Tensor) -> Tensor:
+    """Pos_encoding.forward (model_internals.py:178-206): [cos(t f), sin(t f)] -> Linear -> SiLU -> Linear."""
+    if time_vec.ndim > 1:
+        time_vec = time_vec.flatten()
+    args = time_vec[:, None].float() * P[pre + "freq"][None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    h = F.silu(F.linear(emb, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"]))
+    return F.linear(h, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"])
 
 
 def _sub(P: Params, prefix: str) -> bool:

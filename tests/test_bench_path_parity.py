@@ -50,6 +50,18 @@ def _rel_err(a, b):
     return float((a[fin] - b[fin]).abs().max()) / max(float(b[fin].abs().max()), 1e-30)
 
 
+def _rms_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fin = torch.isfinite(b)
+    return float((a[fin] - b[fin]).pow(2).mean().sqrt()) / max(float(b[fin].pow(2).mean().sqrt()), 1e-30)
+
+
+# bf16 `denoised`: the survey's 2e-2 is met in the RMS sense with a wide margin (measured 2-5e-3); the MAXIMUM over the B x C x H x W outputs is
+# the tail of that rounding noise (each of the ~30 bf16 layers of an expert rounds its output to 8 bits: 2^-9 relative, accumulating as
+# sqrt(layers); the maximum of 16-65 k samples sits at ~4-5 sigma) and is bounded at 3e-2 of the tensor's maximum -- DESIGN.md section 4.
+RMS_TOL_BF16 = 1e-2
+
+
 def _check(g, kw, out, xgrad, pg, tol_out, tol_gate, tol_grad, tag):
     """Outputs / indices / gradients of one step against the reference fixture; returns the measured relative errors."""
     k = kw["top_k"]
@@ -67,6 +79,9 @@ def _check(g, kw, out, xgrad, pg, tol_out, tol_gate, tol_grad, tag):
         e = errs[f"out_{key}"] = _rel_err(out[key], ref)
         tol = tol_gate if key == "out_gate" else (1e-3 if key in ("Unet_raw", "vit_raw", "Unet_router_loss", "vit_router_loss") else tol_out)
         assert e <= tol, f"{tag}: {key} rel err {e:.3e} > {tol:.1e}"
+        if key == "denoised":
+            r = errs["rms_denoised"] = _rms_err(out[key], ref)
+            assert r <= min(RMS_TOL_BF16, tol_out), f"{tag}: denoised RMS rel err {r:.3e}"
     errs["x_grad"] = _rel_err(xgrad, g["x_grad"])
     assert errs["x_grad"] <= tol_grad, f"{tag}: x_grad {errs['x_grad']:.3e}"
     for n, gref in g["param_grads"].items():
@@ -94,6 +109,9 @@ def _setup(g, dtype, train=False):
     inp = {k_: v.to(DEV) for k_, v in inp.items()}
     return model, kw, inp
 
+
+# the scalar loss (sigma-weighted MSE + router terms) in bf16 mode, relative: measured <= 1.2e-2 on the four fixtures, eagerly and replayed
+LOSS_TOL_BF16 = 3e-2
 
 MODES = [("fp32", torch.float32, True, 1e-4, 1e-4, 3e-4), ("bf16_trunkbwd_bf16", torch.bfloat16, True, 3e-2, 6e-2, 6e-2),
          ("bf16_trunkbwd_3prod", torch.bfloat16, False, 3e-2, 6e-2, 6e-2)]
@@ -126,9 +144,11 @@ def test_bank_path_third_step_matches_the_reference(golden_wide, mode, dtype, tr
             assert ops.STATS["trunk"] == 2 and ops.STATS["trunk_bwd"] == 6, dict(ops.STATS)
             if g["cfg_id"] in (1, 2):                          # 3x3 / 5x5 experts: fused dgrad + wgrad launches (7x7 layers take the separate kernels)
                 assert ops.STATS["bwd6"] + ops.STATS["blk_bwd"] >= 20, dict(ops.STATS)
-        torch.testing.assert_close(loss["loss"].detach().cpu(), g["loss"]["loss"], rtol=10 * tol_out, atol=1e-4)
+        loss_tol = 1e-3 if dtype == torch.float32 else LOSS_TOL_BF16
+        torch.testing.assert_close(loss["loss"].detach().cpu(), g["loss"]["loss"], rtol=loss_tol, atol=1e-4)
         pg = {n: p.grad for n, p in model.named_parameters()}
         _measured[f"eager_cfg{g['cfg_id']}_{mode}"] = _check(g, kw, out, x.grad, pg, tol_out, tol_gate, tol_grad, f"cfg{g['cfg_id']} {mode}")
+        _measured[f"eager_cfg{g['cfg_id']}_{mode}"]["loss_rel"] = abs(float(loss["loss"]) - float(g["loss"]["loss"])) / abs(float(g["loss"]["loss"]))
     finally:
         ops.TRUNK_BWD_BF16 = prev
         hdmoe_hip.set_compute_dtype(torch.float32)
@@ -179,7 +199,7 @@ def test_staged_train_mode_replay_matches_the_reference(golden_wide, split_route
         for _ in range(3):
             l_g = staged()
         torch.cuda.synchronize()
-        torch.testing.assert_close(l_g.cpu(), g["loss"]["loss"], rtol=0.2, atol=1e-4)   # (the loss divides by exp(log_var) ~ sigma-weighted sums of bf16 errors)
+        torch.testing.assert_close(l_g.cpu(), g["loss"]["loss"], rtol=LOSS_TOL_BF16, atol=1e-4)     # the same bound as the eager bf16 test
         pg = {n: p.grad for n, p in model.named_parameters()}
         # train() mode replaces every stored MP_Conv weight by normalize(w) before it is used (reference model_internals.py:254-256), so
         # the gradient is taken with respect to the re-normalised tensor: row o of it is the eval-mode gradient (the fixture's) times
@@ -194,5 +214,6 @@ def test_staged_train_mode_replay_matches_the_reference(golden_wide, split_route
                 gfix["param_grads"][n] = gref * fac.view(-1, *([1] * (gref.ndim - 1)))
         tag = f"staged_cfg{g['cfg_id']}_{'ten' if split_router else 'seven'}_graphs"
         _measured[tag] = _check(gfix, kw, keep["out"], x.grad, pg, 3e-2, 1e-1, 6e-2, tag)
+        _measured[tag]["loss_rel"] = abs(float(l_g) - float(g["loss"]["loss"])) / abs(float(g["loss"]["loss"]))
     finally:
         hdmoe_hip.set_compute_dtype(torch.float32)

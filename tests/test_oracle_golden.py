@@ -223,3 +223,48 @@ def test_product_mask_generator_matches_reference(golden_components):
     mg = U.MaskGenerator(expert_attributes=c["attrs"], p_mean=c["p_mean"], p_std=c["p_std"], bandwidth=c["bandwidth"], max_bandwidth=0.8,
                          min_active=1, total_steps=5000, step_size=0.1, noise_range=c["noise_range"], strat_band="step")
     assert torch.equal(mg(c["sigma"], 0), c["out"])
+
+
+def test_round4_boundary_cases():
+    """tests/golden/round4.pt (oracle/make_golden.py round4_pins, from the reference): non-square U-Net expert, Pos_encoding, FIR resampling,
+    general normalize / mp_cat arguments, strided MP_Conv."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round4.pt"), weights_only=False)
+    c = g["unet_expert_64x128"]
+    P = {k: v.clone().requires_grad_(True) for k, v in c["state"].items()}
+    x = c["x"].clone().requires_grad_(True)
+    out = O.unet_expert(P, "", x, c["te"], c["text"])
+    assert out.shape == (1, 4, 64, 128)
+    close(out, c["out"], rtol=1e-4, atol=1e-4)
+    out.backward(c["grad_out"])
+    close_scaled(x.grad, c["x_grad"])
+    for n, gref in c["param_grads"].items():
+        close_scaled(P[n].grad, gref)
+    c = g["unet_expert_half"]
+    close(O.unet_expert(c["state"], "", c["x"], c["te"], c["text"]), c["out_fp32"], rtol=1e-4, atol=1e-4)
+    c = g["pos_encoding"]
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and k != "freq") for k, v in c["state"].items()}
+    out = O.pos_encoding(P, "", c["t"])
+    close(out, c["out"], rtol=1e-5, atol=1e-6)
+    out.backward(c["grad_out"])
+    for n, gref in c["param_grads"].items():
+        close(P[n].grad, gref, rtol=1e-4, atol=1e-6)
+    close(O.pos_encoding(c["state"], "", c["t"].reshape(5, 1)), c["out_2d"], rtol=1e-5, atol=1e-6)
+    c = g["normalize_eps"]
+    close(O.normalize(c["x"], eps=c["eps"]), c["out"])
+    c = g["normalize_dim23"]
+    close(O.normalize(c["x"], dim=c["dim"]), c["out"])
+    c = g["normalize_dim1_eps"]
+    close(O.normalize(c["x"], dim=c["dim"], eps=c["eps"]), c["out"])
+    for k in ("mp_cat_dim0", "mp_cat_dim2"):
+        c = g[k]
+        close(O.mp_cat(c["a"], c["b"], dim=c["dim"], t=c["t"]), c["out"])
+    for mode in ("down", "up"):
+        c = g[f"resample_f1331_{mode}"]
+        x = c["x"].clone().requires_grad_(True)
+        o = O.resample(x, mode, f=c["f"])
+        close(o, c["out"])
+        o.backward(c["grad_out"])
+        close(x.grad, c["x_grad"])
+    c = g["mp_conv_stride2"]
+    close(O.mp_conv(c["x"], c["state"]["weights"], c["gain"], stride=2), c["out"], rtol=1e-5, atol=1e-6)
