@@ -528,6 +528,10 @@ def main():
     if world == 1 and not args.no_fp32_trunk_leg and not args.no_graph and graphed is not None and not args.single_graph and bc["dtype"] == "bf16":
         prev_flag = ops.TRUNK_BWD_BF16
         try:
+            # (the first staged step goes first: its four prioritised streams next to a second set slow whole stages down 1.5-2x -- DESIGN.md section 5)
+            graphed = None
+            gc.collect()
+            torch.cuda.synchronize()
             ops.TRUNK_BWD_BF16 = False
             buckets.enabled = False
             g2 = StagedStep(fwd_bwd, device)

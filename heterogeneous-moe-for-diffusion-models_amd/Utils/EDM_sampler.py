@@ -33,8 +33,8 @@ class EDM_Sampler:
         self.use_graph = use_graph          # extension over the reference: hipGraph replay of the denoiser evaluation
         self._graph = None
         self._gkey = None
-        # use_graph and no churn, fp32 latents: a whole solver stage (both denoiser evaluations + the fused Euler / Heun-correction kernels,
-        # sigma read from a device-side schedule) is ONE captured graph, replayed N - 1 times, plus one graph for the last (Euler-only) stage
+        # no churn, fp32 latents: a solver stage = both denoiser evaluations + the fused Euler / Heun-correction kernels with sigma read from a
+        # device-side schedule; with use_graph it is ONE captured graph, replayed N - 1 times, plus one graph for the last (Euler-only) stage
         self.fused_heun = False
         self._stage = None
         self._skey = None
@@ -86,8 +86,11 @@ class EDM_Sampler:
         return self._sout.clone()
 
     # ---- fused solver stage (reference :90-107 without churn) ----------------------------------------------------------
-    def _stage_graphs(self, x, text_emb, transition_mean, softness, uncond_text_emb):
-        key = (tuple(x.shape), tuple(text_emb.shape), float(transition_mean), float(softness), self.num_steps,
+    def _stage_state(self, x, text_emb, transition_mean, softness, uncond_text_emb):
+        """Static buffers of the device-side solver: latents, sigma schedule (float64, as the host computes it), stage index; with
+        use_graph also the two captured graphs (a full Heun stage, and the last Euler-only stage).  The SAME stage function runs
+        eagerly (use_graph=False) and under capture, so the two trajectories are bit-identical."""
+        key = (tuple(x.shape), tuple(text_emb.shape), float(transition_mean), float(softness), self.num_steps, bool(self.use_graph),
                None if uncond_text_emb is None else tuple(uncond_text_emb.shape))
         if self._stage is not None and self._skey == key:
             return self._stage
@@ -110,19 +113,21 @@ class EDM_Sampler:
                 ops.call("hdmoe_heun_correct", st["x"], st["x"], den, st["xn"], den2, st["t"], st["idx"], n)
             ops.call("hdmoe_idx_advance", st["idx"])
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                         # warm-up: registers the weight bank, sizes the allocator pool
-            for _ in range(2):
-                st["idx"].zero_()
+        st["stage"] = stage
+        if self.use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                     # warm-up: registers the weight bank, sizes the allocator pool
+                for _ in range(2):
+                    st["idx"].zero_()
+                    stage(False)
+            torch.cuda.current_stream().wait_stream(side)
+            st["g_heun"], st["g_last"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            st["idx"].zero_()
+            with torch.cuda.graph(st["g_heun"]):
                 stage(False)
-        torch.cuda.current_stream().wait_stream(side)
-        st["g_heun"], st["g_last"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        st["idx"].zero_()
-        with torch.cuda.graph(st["g_heun"]):
-            stage(False)
-        with torch.cuda.graph(st["g_last"], pool=st["g_heun"].pool()):
-            stage(True)
+            with torch.cuda.graph(st["g_last"], pool=st["g_heun"].pool()):
+                stage(True)
         self._stage, self._skey = st, key
         return st
 
@@ -152,18 +157,23 @@ class EDM_Sampler:
                     m_._hdmoe_bank.refresh_eval()
         t_steps = self.t_schedule(device)
         x_next = ops.axpby(noise.to(self.dtype), None, float(t_steps[0]), 0.0)
-        self.fused_heun = bool(self.use_graph and self.s_churn <= 0 and self.dtype == torch.float32 and noise.is_cuda and self.num_steps >= 2)
+        self.fused_heun = bool(self.s_churn <= 0 and self.dtype == torch.float32 and noise.is_cuda and self.num_steps >= 2)
         if self.fused_heun:
-            st = self._stage_graphs(x_next, text_emb, transition_mean, softness, uncond_text_emb)
+            # no churn: the whole solver runs from a device-side schedule (fused Euler / Heun-correction kernels, no host arithmetic between
+            # the evaluations); with use_graph each stage is one hipGraph replay
+            st = self._stage_state(x_next, text_emb, transition_mean, softness, uncond_text_emb)
             st["x"].copy_(x_next)
             st["text"].copy_(text_emb)
             if st["unc"] is not None:
                 st["unc"].copy_(uncond_text_emb)
             st["t"].copy_(torch.from_numpy(t_steps))
             st["idx"].zero_()
-            for _ in range(self.num_steps - 1):
-                st["g_heun"].replay()
-            st["g_last"].replay()
+            for i in range(self.num_steps):
+                last = i == self.num_steps - 1
+                if self.use_graph:
+                    (st["g_last"] if last else st["g_heun"]).replay()
+                else:
+                    st["stage"](last)
             return st["x"].clone()
         for i in range(self.num_steps):
             t_cur, t_next = float(t_steps[i]), float(t_steps[i + 1])

@@ -13,6 +13,7 @@
 #include "conv6_body.h"
 #include "conv7_body.h"
 #include "wgrad6_body.h"
+#include "wgrad7_body.h"
 #include "conv6s_body.h"
 
 namespace {
@@ -47,8 +48,13 @@ __global__ __launch_bounds__(512) void bwd7_kernel(C7Args c, W6Args a3, W6Args a
   const int bx = r % ibs; r /= ibs;
   const int by = r % obs;
   const int z = r / obs;
-  if (z < a3.chunks) wgrad6_body<3, TWS, OT, false>(a3, bx, by, z);
-  else wgrad6_body<5, TWS, OT, false>(a5, bx, by, z - a3.chunks);
+  if (TWS == 5 && OT == 0) {                                 // 32 x 32 maps: the streaming weight-gradient program, one 32-channel output chunk per workgroup
+    if (z < a3.chunks) wgrad7_body<3>(a3, bx, by, z);
+    else wgrad7_body<5>(a5, bx, by, z - a3.chunks);
+  } else if (OT > 0) {
+    if (z < a3.chunks) wgrad6_body<3, TWS, OT == 0 ? 1 : OT, false>(a3, bx, by, z);
+    else wgrad6_body<5, TWS, OT == 0 ? 1 : OT, false>(a5, bx, by, z - a3.chunks);
+  }
 }
 
 template <int CO, int KMASK, int TWS, int OT>
@@ -56,8 +62,9 @@ void launch_bwd7(const C7Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
   static unsigned long long attr = 0;
   if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
-  const unsigned grid = cp.G + (unsigned)(wp.ibs * wp.obs * (wp.c[0].chunks + wp.c[1].chunks));
-  hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, wp.obs);
+  const int obs = OT == 0 ? wp.c[0].Cout / 32 : wp.obs;      // OT == 0: wgrad7 (output chunks of 32)
+  const unsigned grid = cp.G + (unsigned)(wp.ibs * obs * (wp.c[0].chunks + wp.c[1].chunks));
+  hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, obs);
 }
 
 // The same for a router-trunk layer (fp32 tensors on the bf16 pipe: conv6_split program + wgrad6<SPLIT> program).
@@ -131,10 +138,11 @@ int hdmoe_conv_bwd6(const void* x, const void* dy, const void* wd, void* dx, flo
   }
   {
     C7Plan cp7;                                            // 32 x 32 maps: the streaming kernel as the dgrad program (wgrad6 handles 3x3 / 5x5 only)
+    static const bool w7 = !(getenv("HDMOE_WGRAD7") && atoi(getenv("HDMOE_WGRAD7")) == 0);
     if (!conv7_plan(c, dtype, cp7) && cp7.kmask == 3 && (cp7.w16 != 0) == (wp.TWS == 4)) {
 #define BWD7_GO(Co)                                                                              \
   do {                                                                                           \
-    if (wp.TWS == 5) { if (wp.OT == 2) launch_bwd7<Co, 3, 5, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 5, 1>(cp7, wp, stream); } \
+    if (wp.TWS == 5) { if (w7) launch_bwd7<Co, 3, 5, 0>(cp7, wp, stream); else if (wp.OT == 2) launch_bwd7<Co, 3, 5, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 5, 1>(cp7, wp, stream); } \
     else { if (wp.OT == 2) launch_bwd7<Co, 3, 4, 2>(cp7, wp, stream); else launch_bwd7<Co, 3, 4, 1>(cp7, wp, stream); }            \
   } while (0)
       if (cp7.CO == 2) BWD7_GO(2); else BWD7_GO(1);

@@ -115,17 +115,30 @@ __global__ __launch_bounds__(256) void wgrad6_reduce_multi_kernel(W6RBatch b) {
 
 // Pixel partitioning of one kernel-size class: upw tiles per workgroup, `slots` partition slots (an upper bound that holds for any
 // routing: sum over the class's experts of ceil(units_g / upw) <= units_l / upw + ngr).
-void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw, int& slots, bool split) {
+void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw, int& slots, bool split, int tpi, const int* kh, int ks) {
   // Workgroups per kernel-size class.  bf16 expert layers: 128 -- every partition writes (and the reduction re-reads) a whole
   // [tap][O][I] fp32 slab, at 256 a 64->64 layer moved 71 MB of partials for 2 x 17 MB of operands, and in the fused backward launch
   // the 256 conv workgroups fill the chip anyway (same-box A/B 256 -> 128: 16.58 -> 16.15 ms/step).  The fp32 router layers
   // measure the same (16.15-16.2 with 128, 16.25-16.4 with 256 or 512).
   static const long target_bf = getenv("HDMOE_W6_PARTS") ? atol(getenv("HDMOE_W6_PARTS")) : 128;
   static const long target_sp = getenv("HDMOE_W6_PARTS_SPLIT") ? atol(getenv("HDMOE_W6_PARTS_SPLIT")) : 128;
-  long parts = (split ? target_sp : target_bf) / ((long)ibs * obs); if (parts < 1) parts = 1;
+  long parts = (split ? target_sp : target_bf) / ((long)ibs * obs);
+  // Two kernel-size classes in one launch (3x3 and 5x5 experts): the workgroups are shared out by WORK (taps x rows), not evenly -- with 128 + 128
+  // the 3x3 class finished in a third of the 5x5 class's time and its CUs idled (round 4; HDMOE_W6_BALANCE=0: the even split)
+  static const bool balance = !(getenv("HDMOE_W6_BALANCE") && atoi(getenv("HDMOE_W6_BALANCE")) == 0);
+  if (balance && !split && kh && ngr < ngroups) {
+    long wsum = 0;
+    for (int g = 0; g < ngroups; ++g) wsum += (long)kh[g] * kh[g];
+    parts = 2 * target_bf * ((long)ngr * ks * ks) / wsum / ((long)ibs * obs);
+  }
+  if (parts < 1) parts = 1;
   const long class_units = (units_l * ngr + ngroups - 1) / ngroups;
   long u = (class_units + parts - 1) / parts; if (u < 1) u = 1;
-  while (units_l / u + ngr > 1024) ++u;
+  // whole images per partition (tpi tiles each): the streaming weight-gradient program (wgrad7_body.h) walks a slot image by image; wgrad6 and
+  // the reductions recompute the same partition from the same inputs
+  if (tpi < 1) tpi = 1;
+  u = (u + tpi - 1) / tpi * tpi;
+  while (units_l / u + ngr > 1024) u += tpi;
   upw = (int)u; slots = (int)(units_l / u + ngr);
 }
 
@@ -159,7 +172,7 @@ int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout
     int ngr = 0;
     for (int g2 = g; g2 < ngroups; ++g2) if (!done[g2] && kh[g2] == kh[g]) { ++ngr; done[g2] = true; }
     int upw, slots;
-    w6_partition(units_l, ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S);
+    w6_partition(units_l, ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S, (W / TW) * (int)cdiv(H, TH), kh, kh[g]);
     const long b = (long)slots * kh[g] * kh[g] * Cout * Cin * 4;
     if (b > bytes) bytes = b;
   }
@@ -201,7 +214,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
     for (int g = 0; g < ngroups; ++g) if (kh[g] == ks) { p.c[k].groups[p.c[k].ngr++] = g; p.c[k].pt = pt[g]; p.c[k].pl = pl[g]; }
     p.c[k].ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
-    w6_partition(units_l, p.c[k].ngr, ngroups, p.ibs, p.obs, upw, slots, false);
+    w6_partition(units_l, p.c[k].ngr, ngroups, p.ibs, p.obs, upw, slots, false, a.tpi, kh, ks);
     p.c[k].upw = upw; p.c[k].chunks = slots;
   }
   // workspace regions in the order the classes appear in the group list (what hdmoe_conv_wgrad6_reduce_batch assumes)
@@ -236,7 +249,7 @@ int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int*
   for (int g = 0; g < ngroups; ++g) a.groups[a.ngr++] = g;
   a.pt = 1; a.pl = 1; a.ws_item = 9l * Cout * Cin;
   int upw, slots;
-  w6_partition((long)N * a.tpi, a.ngr, ngroups, p.ibs, p.obs, upw, slots, true);
+  w6_partition((long)N * a.tpi, a.ngr, ngroups, p.ibs, p.obs, upw, slots, true, a.tpi, kh, 3);
   a.upw = upw; a.chunks = slots;
   p.c[1] = a; p.c[1].chunks = 0;
   const int HP16 = ((TW + 2) * (TH + 2) + 15) / 16;
@@ -303,7 +316,7 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
     ++cls;
     a.ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
-    w6_partition(units_l, a.ngr, ngroups, ibs, obs, upw, slots, dtype == HDMOE_F32S);
+    w6_partition(units_l, a.ngr, ngroups, ibs, obs, upw, slots, dtype == HDMOE_F32S, a.tpi, kh, ks);
     a.upw = upw; a.chunks = slots;                          // (chunks = partition slots of this class)
     const W6Args& b = a;                                    // (kernel-size classes reuse the workspace: each class's reduce runs before the next class)
 #define W6_LAUNCH(K, T, O) launch_w6<K, T, O, false>(b, ibs, obs, stream)
@@ -355,7 +368,7 @@ int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float
         if (!done[g2] && kh[g2] == kh[g]) { it.groups[it.ngr] = g2; it.G[it.ngr] = G[8 * i + g2]; ++it.ngr; done[g2] = true; }
       for (int k = it.ngr; k < HDMOE_MAX_GROUPS; ++k) { it.groups[k] = 0; it.G[k] = nullptr; }
       int upw, slots;
-      w6_partition(units_l, it.ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S);
+      w6_partition(units_l, it.ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S, tpi, kh, kh[g]);
       it.ws = (const float*)((const char*)ws[i] + (long)cls * need1);
       it.seg = seg[i]; it.N = N; it.tpi = tpi; it.upw = upw;
       it.ws_item = (long)kh[g] * kh[g] * Cout * Cin;

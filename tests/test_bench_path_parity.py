@@ -56,10 +56,11 @@ def _rms_err(a, b):
     return float((a[fin] - b[fin]).pow(2).mean().sqrt()) / max(float(b[fin].pow(2).mean().sqrt()), 1e-30)
 
 
-# bf16 `denoised`: the survey's 2e-2 is met in the RMS sense with a wide margin (measured 2-5e-3); the MAXIMUM over the B x C x H x W outputs is
-# the tail of that rounding noise (each of the ~30 bf16 layers of an expert rounds its output to 8 bits: 2^-9 relative, accumulating as
-# sqrt(layers); the maximum of 16-65 k samples sits at ~4-5 sigma) and is bounded at 3e-2 of the tensor's maximum -- DESIGN.md section 4.
-RMS_TOL_BF16 = 1e-2
+# bf16 `denoised`: the survey's 2e-2 is asserted on the RMS error relative to the tensor's RMS (the natural reading of an rtol on a tensor whose
+# entries pass through zero; measured values in profiles/r04_bench_path_parity.json); the MAXIMUM error over the B x C x H x W outputs is bounded at
+# 3e-2 of the tensor's maximum (each of the ~30 bf16 layers of an expert rounds its output to 8 bits, 2^-9 relative, accumulating roughly as
+# sqrt(layers); the maximum over 16-65 k outputs is the tail of that noise) -- DESIGN.md section 4.
+RMS_TOL_BF16 = 2e-2
 
 
 def _check(g, kw, out, xgrad, pg, tol_out, tol_gate, tol_grad, tag):
@@ -110,8 +111,8 @@ def _setup(g, dtype, train=False):
     return model, kw, inp
 
 
-# the scalar loss (sigma-weighted MSE + router terms) in bf16 mode, relative: measured <= 1.2e-2 on the four fixtures, eagerly and replayed
-LOSS_TOL_BF16 = 3e-2
+# the scalar loss (sigma-weighted MSE + router terms) in bf16 mode, relative: measured <= 4.7e-3 on the four fixtures, eagerly and replayed
+LOSS_TOL_BF16 = 1e-2
 
 MODES = [("fp32", torch.float32, True, 1e-4, 1e-4, 3e-4), ("bf16_trunkbwd_bf16", torch.bfloat16, True, 3e-2, 6e-2, 6e-2),
          ("bf16_trunkbwd_3prod", torch.bfloat16, False, 3e-2, 6e-2, 6e-2)]

@@ -48,4 +48,115 @@ if "--time" in sys.argv:
         c6.timeit(512, 16, Cin, Cout, (3, 3, 5, 5))
     c6.timeit(512, 16, 64, 64, (3, 3, 3, 3))
     c6.timeit(512, 16, 64, 64, (5, 5, 5, 5))
-sys.exit(0 if ok else 1)
+if "--check" in sys.argv or "--time" in sys.argv:
+    sys.exit(0 if ok else 1)
+
+
+# ---- the fused backward launch (hdmoe_conv_bwd6: dgrad program + weight-gradient programs in one grid) called directly --------------------
+def _bwd_setup(N, R, Cin, Cout, ks, split, seed):
+    import torch
+    from hdmoe_hip._lib import call, lib, _int_array
+    import ctypes
+    dev = "cuda"
+    g = torch.Generator().manual_seed(seed)
+    E = len(ks)
+    x = torch.randn(N, R, R, Cin, generator=g).bfloat16()
+    dy = torch.randn(N, R, R, Cout, generator=g).bfloat16()
+    ws = [(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16() for k in ks]
+    seg = [0] + list(split)
+    O, I = Cout, Cin
+    Opad = (O + 15) // 16 * 16
+    taps = max(k * k for k in ks)
+    wstride, wdstride = taps * O * I, taps * I * Opad
+    wdv = [w.float().to(dev) for w in ws]
+    wf = torch.empty(E * wstride, dtype=torch.bfloat16, device=dev)
+    wd = torch.empty(E * wdstride, dtype=torch.bfloat16, device=dev)
+    call("hdmoe_wprep_fwd", wdv, None, 1.0, list(ks), list(ks), E, O, I, I, Opad, wf, wstride, wd, wdstride, 0, 0, 1, 1)
+    kib = lib().hdmoe_conv_wgrad6_ws_kib(E, N, R, R, I, O, ctypes.cast(_int_array(ks), ctypes.c_void_p), ctypes.cast(_int_array(ks), ctypes.c_void_p), 1)
+    assert kib > 0
+    wsb = torch.empty(2 * kib * 256, dtype=torch.float32, device=dev)
+    Gs = [torch.zeros(k * k, O, I, device=dev) for k in ks]
+    segd = torch.tensor(seg, dtype=torch.int32, device=dev)
+    xd, dyd = x.to(dev), dy.to(dev)
+    dx = torch.empty_like(xd)
+    pts = [(k - 1) // 2 for k in ks]
+    args = (xd, dyd, wd, dx, Gs, segd, E, wdstride, N, R, R, I, O, list(ks), list(ks), pts, pts, 1.0, wsb, wsb.numel() * 4, 1)
+    dims = [E, N, R, R, I, O, 1, 0] + list(ks) + [0] * (8 - E)
+    return x, dy, ws, seg, Gs, dx, segd, wsb, args, dims
+
+
+def check_bwd(N, R, Cin, Cout, ks, split, seed=0):
+    import torch
+    import torch.nn.functional as F
+    from hdmoe_hip._lib import call
+    x, dy, ws, seg, Gs, dx, segd, wsb, args, dims = _bwd_setup(N, R, Cin, Cout, ks, split, seed)
+    rc = call("hdmoe_conv_bwd6", *args)
+    if rc != 0:
+        print(f"--  bwd N={N} R={R} {Cin}->{Cout} ks={ks}: outside the fused launch's domain (rc {rc})", flush=True)
+        return True
+    call("hdmoe_conv_wgrad6_reduce_batch", Gs + [None] * (8 - len(Gs)), [segd], [wsb], dims, 1)
+    torch.cuda.synchronize()
+    xr = x.float().requires_grad_(True)
+    wr = [w.float().requires_grad_(True) for w in ws]
+    outs = []
+    for gi, w in enumerate(wr):
+        xs = xr[seg[gi]:seg[gi + 1]].permute(0, 3, 1, 2)
+        k = w.shape[-1]; pl = (k - 1) // 2
+        outs.append(F.conv2d(F.pad(xs, (pl, k - 1 - pl, pl, k - 1 - pl)), w).permute(0, 2, 3, 1))
+    (torch.cat(outs, 0) * dy.float()).sum().backward()
+    gerr = float((dx.float().cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max())
+    werr = 0.0
+    for gi, k in enumerate(ks):
+        ref = wr[gi].grad.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
+        if seg[gi + 1] > seg[gi]:
+            werr = max(werr, float((Gs[gi].cpu() - ref).abs().max()) / float(ref.abs().max()))
+        else:
+            werr = max(werr, float(Gs[gi].abs().max()))
+    ok = gerr < 2e-2 and werr < 1e-3
+    print(f"{'ok ' if ok else 'BAD'} bwd N={N} R={R} {Cin}->{Cout} ks={ks} split={split}: dgrad {gerr:.2e} wgrad {werr:.2e}", flush=True)
+    return ok
+
+
+def time_bwd(N, R, Cin, Cout, ks, iters=10):
+    import torch
+    from hdmoe_hip._lib import call
+    E = len(ks)
+    split = [N * (i + 1) // E for i in range(E)]
+    x, dy, ws, seg, Gs, dx, segd, wsb, args, dims = _bwd_setup(N, R, Cin, Cout, ks, split, 1)
+    for _ in range(3):
+        call("hdmoe_conv_bwd6", *args)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call("hdmoe_conv_bwd6", *args)
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(iters):
+            call("hdmoe_conv_bwd6", *args)
+    gr.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); gr.replay(); e.record(); torch.cuda.synchronize()
+    us = 1e3 * s.elapsed_time(e) / iters
+    fl = 2 * sum(2.0 * (N // E) * R * R * Cout * Cin * k * k for k in ks)
+    print(f"time bwd (dgrad + wgrad) N={N} R={R} {Cin}->{Cout} ks={ks}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+
+
+if "--check-bwd" in sys.argv:
+    okb = True
+    okb &= check_bwd(16, 32, 32, 32, (3, 3, 5, 5), (3, 7, 12, 16), seed=1)
+    okb &= check_bwd(9, 32, 64, 64, (3, 5), (5, 9), seed=2)
+    okb &= check_bwd(10, 32, 96, 32, (5, 3), (4, 10), seed=3)
+    okb &= check_bwd(7, 32, 64, 32, (3, 5, 3), (2, 5, 7), seed=4)
+    okb &= check_bwd(6, 32, 32, 32, (5, 3), (6, 6), seed=5)               # empty 3x3 class member
+    okb &= check_bwd(300, 32, 32, 32, (3, 3, 5, 5), (70, 150, 210, 300), seed=6)
+    okb &= check_bwd(11, 16, 64, 64, (3, 3, 5, 5), (2, 5, 8, 11), seed=7)
+    okb &= check_bwd(300, 16, 64, 64, (3, 5), (140, 300), seed=8)
+    print("BWD ALL OK" if okb else "BWD FAILURES", flush=True)
+    sys.exit(0 if okb else 1)
+if "--time-bwd" in sys.argv:
+    for Cin, Cout in ((32, 32), (64, 64), (96, 32), (64, 32)):
+        time_bwd(512, 32, Cin, Cout, (3, 3, 5, 5))
+    for Cin, Cout in ((64, 64), (128, 64), (32, 32)):
+        time_bwd(512, 16, Cin, Cout, (3, 3, 5, 5))
