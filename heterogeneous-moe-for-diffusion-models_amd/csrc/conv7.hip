@@ -1,7 +1,7 @@
 // K3 (third generation): whole-image streaming convolution for the k x k expert layers on 32 x 32 feature maps -- forward and dgrad of
 // MP_Conv (reference models/model_internals.py:253-275), all experts of a layer in one launch (models/model_config1.py:25-37).
 // Design notes: conv7_body.h.  Domain: bf16, stride 1, H = W = 32 or H = W = 16, square k in {3, 5, 7} with "same" padding (k - 1) / 2,
-// Cin % 32 == 0 (<= 256), Cout in {32, 64}, at least HDMOE_C7_MINN images (a unit is a whole image: fewer images than CUs leave CUs idle,
+// Cin % 32 == 0 (<= 256), Cout % 32 == 0 (<= 256), at least HDMOE_C7_MINN images (a unit is a whole image: fewer images than CUs leave CUs idle,
 // conv6's 256-pixel units fill the chip better then).  Everything else stays on conv6 / conv.hip.
 #include <stdlib.h>
 #include "conv_args.h"
@@ -21,7 +21,7 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
   static const int minn = getenv("HDMOE_C7_MINN") ? atoi(getenv("HDMOE_C7_MINN")) : 192;
   if (off) return 1;
   if (dtype != HDMOE_BF16 || c.stride != 1 || c.ones || c.Cphys != c.Cin || c.Ipad != c.Cin || c.Cin % 32 || c.Cin > 256 || c.Cstore != c.Cout) return 1;
-  if (c.Cout != 32 && c.Cout != 64) return 1;
+  if (c.Cout % 32 || c.Cout > 256) return 1;                 // (more than 64 output channels: blocks of 64 / 32 walked over the same image)
   const bool w16 = c.H == 16;
   if (!((c.H == 32 && c.W == 32) || (c.H == 16 && c.W == 16)) || c.Ho != c.H || c.Wo != c.W || c.N < minn) return 1;
   int kmask = 0;
@@ -49,7 +49,7 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
   const long gcap = gcap_env > 0 ? gcap_env : 256;
   const long units = w16 ? (c.N + 1) / 2 + c.ngroups : c.N;    // (16 x 16: pairs of images of one expert; an upper bound for any routing)
   plan.G = (unsigned)(units < gcap ? units : gcap);
-  plan.CO = c.Cout / 32;
+  plan.CO = c.Cout % 64 == 0 ? 2 : 1;
   plan.w16 = w16 ? 1 : 0;
   plan.lds = w16 ? C7Lds<true>::BYTES : C7Lds<false>::BYTES;
   plan.kmask = (kmask & 4) ? 7 : 3;                          // instantiated kernel-size sets: {3, 5} and {3, 5, 7}

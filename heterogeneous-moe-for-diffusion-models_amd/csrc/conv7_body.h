@@ -157,14 +157,14 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
     }
   };
   // this wave's pieces of the weight stage (kernel column kx, rows ky0 .. ky0 + nt) of chunk c, group g, kernel size ks -> ring buffer sp
-  auto issue_wstage = [&](int g, int ks, int c, int kx, int ky0, int nt, int sp) {
+  auto issue_wstage = [&](int g, int ks, int c, int blk, int kx, int ky0, int nt, int sp) {
 #pragma unroll
     for (int j = 0; j < (2 * TCO + 7) / 8; ++j) {
       const int pi = wave + 8 * j;
       const int ts = pi / (2 * CO), pc = pi % (2 * CO);         // tap slot, 16-row piece inside the tap
       if (ts < nt) {
         const int tap = (ky0 + ts) * ks + kx;
-        const int so = (int)(((long)g * a.wstride + (long)(tap * a.Cout + pc * 16) * a.Cin) * 2) + c * 64;
+        const int so = (int)(((long)g * a.wstride + (long)(tap * a.Cout + blk * 32 * CO + pc * 16) * a.Cin) * 2) + c * 64;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c7_lptr_t)(lds + sp * WBUF + pi * 1024), 16, wlane, so, 0, 0);
       }
     }
@@ -176,7 +176,8 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
   bool has_next = unit_at(q + 1, nxt);
   int tp = 0, sp = 0;                                           // tile / weight ring parity
   auto nt0_of = [](int ks) { return ks == 3 ? C7Sched<3, CO, GEO::TCO>::nt(0) : (ks == 5 ? C7Sched<5, CO, GEO::TCO>::nt(0) : C7Sched<7, CO, GEO::TCO>::nt(0)); };
-  issue_wstage(cur.g, cur.ks, 0, 0, 0, nt0_of(cur.ks), 0);       // first stage of the unit's schedule: column 0, rows 0 .. nt0
+  const int nblk = a.Cout / (32 * CO);                          // output-channel blocks of 32 CO: walked one after the other over the same image
+  issue_wstage(cur.g, cur.ks, 0, 0, 0, 0, nt0_of(cur.ks), 0);    // first stage of the unit's schedule: column 0, rows 0 .. nt0
   issue_tile(cur, 0, 0);
   bool first = true;
 
@@ -185,6 +186,8 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
     constexpr int KS = decltype(ks_tag)::value;
     using S = C7Sched<KS, CO, TCO>;
     constexpr int P = (KS - 1) / 2, Q = 3 - P;
+    for (int blk = 0; blk < nblk; ++blk) {
+    const bool last_blk = blk == nblk - 1;
     f32x16 acc[MB][CO];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -193,7 +196,10 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 
     for (int c = 0; c < CI; ++c) {
       const bool last_chunk = c == CI - 1;
-      const bool tile_next = (!last_chunk || has_next) && !((a.dbg & 2) && last_chunk);   // a tile is fetched beside this chunk's first stage
+      // the tile fetched beside this chunk's first stage: the unit's next chunk; behind the last chunk the first chunk again for the next
+      // output block (a one-chunk image simply stays where it is), or the next unit's first chunk
+      const bool same_tile = last_chunk && !last_blk && CI == 1;
+      const bool tile_next = (!last_chunk || (!last_blk && CI > 1) || (last_blk && has_next)) && !((a.dbg & 2) && last_chunk);
       const int tbase = T0 + tp * TILE;
 #pragma unroll
       for (int s = 0; s < S::NS; ++s) {
@@ -202,7 +208,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
         // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free.
         //      vmcnt counts in issue order: what may stay in flight is whatever this wave issued AFTER the pieces it needs now
         if (s == 0) {
-          if (c == 0 && !first) c7_wait_barrier<NSTORE>();      // the previous unit's epilogue stores
+          if (c == 0 && !first) c7_wait_barrier<NSTORE>();      // the previous block's / unit's epilogue stores
           else c7_wait_barrier<0>();
         } else if (s == 1 && tile_next) {
           c7_wait_barrier<PPW>();                               // the tile pieces issued behind this stage's weight pieces
@@ -212,14 +218,16 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
         // ---- next stage's weights, next tile
         if (s + 1 < S::NS) {
           const int s1 = s + 1;
-          issue_wstage(cur.g, KS, c, s1 / S::SPC, S::ky0(s1 % S::SPC), S::nt(s1 % S::SPC), sp ^ 1);
+          issue_wstage(cur.g, KS, c, blk, s1 / S::SPC, S::ky0(s1 % S::SPC), S::nt(s1 % S::SPC), sp ^ 1);
         } else if (!last_chunk) {
-          issue_wstage(cur.g, KS, c + 1, 0, S::ky0(0), S::nt(0), sp ^ 1);
+          issue_wstage(cur.g, KS, c + 1, blk, 0, S::ky0(0), S::nt(0), sp ^ 1);
+        } else if (!last_blk) {
+          issue_wstage(cur.g, KS, 0, blk + 1, 0, S::ky0(0), S::nt(0), sp ^ 1);
         } else if (has_next) {
-          issue_wstage(nxt.g, nxt.ks, 0, 0, 0, nt0_of(nxt.ks), sp ^ 1);
+          issue_wstage(nxt.g, nxt.ks, 0, 0, 0, 0, nt0_of(nxt.ks), sp ^ 1);
         }
         if (s == 0 && tile_next) {
-          if (!last_chunk) issue_tile(cur, c + 1, tp ^ 1); else issue_tile(nxt, 0, tp ^ 1);
+          if (!last_chunk) issue_tile(cur, c + 1, tp ^ 1); else if (!last_blk) issue_tile(cur, 0, tp ^ 1); else issue_tile(nxt, 0, tp ^ 1);
         }
         // ---- MFMAs of the stage: per 16-channel k-step, the nt + MB - 1 input rows it touches, then per kernel row its weight fragment(s)
         if (!(a.dbg & 1)) {
@@ -250,8 +258,9 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
         }
         sp ^= 1;
       }
-      tp ^= 1;
+      if (!same_tile) tp ^= 1;
     }
+    const int cobase = blk * 32 * CO;
     // ---- epilogue: y = alpha * acc + beta * res, 16-byte stores (register quads paired across the half-waves)
     if (!(a.dbg & 4)) {
       bf16* Y = (bf16*)a.y;
@@ -270,7 +279,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = a.alpha * acc[m][b][8 * p + e];
             if (R && live) {
-              const long o0 = pix + 32 * b + 16 * p + 4 * h;
+              const long o0 = pix + cobase + 32 * b + 16 * p + 4 * h;
               const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(R + o0);
               const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(R + o0 + 8);
 #pragma unroll
@@ -282,7 +291,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
             const unsigned B0 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[4], (bf16)v[5]}), B1 = __builtin_bit_cast(unsigned, (bf2){(bf16)v[6], (bf16)v[7]});
             const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A0, B0, false, false);
             const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A1, B1, false, false);
-            if (live) *reinterpret_cast<uint4*>(Y + pix + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (live) *reinterpret_cast<uint4*>(Y + pix + cobase + 32 * b + 16 * p + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
       }
     } else {
@@ -291,6 +300,8 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 #pragma unroll
         for (int b = 0; b < CO; ++b) asm volatile("" :: "v"(acc[m][b]));
     }
+    first = false;
+    }                                                           // output blocks
   };
 
   while (true) {

@@ -22,6 +22,8 @@ if "--check" in sys.argv:
         (7, 64, 64, (7, 3), (3, 7), False),
         (6, 32, 32, (5, 7), (6, 6), False),
         (300, 32, 32, (3, 3, 5, 5), (70, 150, 210, 300), True),
+        (10, 32, 96, (3, 3, 5, 5), (2, 5, 7, 10), True),          # three output blocks of 32 over a resident one-chunk image
+        (7, 64, 128, (3, 5), (3, 7), False),                      # two output blocks of 64, the two chunks streamed again per block
     ]
     for N, Cin, Cout, ks, split, res in cases:
         ok &= c6.check(N, 32, Cin, Cout, ks, split, res, seed=N)
@@ -33,6 +35,9 @@ if "--check" in sys.argv:
         (11, 64, 64, (3, 5, 7), (4, 8, 11), True),
         (6, 64, 32, (5, 7), (6, 6), False),
         (301, 64, 64, (3, 3, 5, 5), (70, 151, 210, 301), True),
+        (9, 64, 128, (3, 5), (4, 9), True),
+        (10, 64, 96, (5, 3), (5, 10), False),
+        (5, 32, 160, (3, 7), (2, 5), False),
     ]
     for N, Cin, Cout, ks, split, res in cases16:
         ok &= c6.check(N, 16, Cin, Cout, ks, split, res, seed=N + 1)
