@@ -504,8 +504,32 @@ __global__ void groupnorm_apply_vec_kernel(T* y, const T* x, const float* gamma,
     vstore<T>(y + v * W, f);
   }
 }
-template <typename T>
-__global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const T* dy,
+// W-element vector access for a tensor whose element type differs from the one that sets the vector width (router-trunk backward in bf16
+// mode: fp32 activations, 4 per thread, next to bf16 gradients, 4 per thread = 8 bytes)
+template <typename TD, int W> struct VecW;
+template <> struct VecW<float, 4> {
+  static DEVI void load(float* f, const float* p) { vload<float>(f, p); }
+  static DEVI void store(float* p, const float* f) { vstore<float>(p, f); }
+};
+template <> struct VecW<bf16, 8> {
+  static DEVI void load(float* f, const bf16* p) { vload<bf16>(f, p); }
+  static DEVI void store(bf16* p, const float* f) { vstore<bf16>(p, f); }
+};
+template <> struct VecW<bf16, 4> {
+  static DEVI void load(float* f, const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
+  }
+  static DEVI void store(bf16* p, const float* f) {
+    bf16x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (bf16)f[j];
+    *reinterpret_cast<bf16x4*>(p) = v;
+  }
+};
+template <typename T, typename TD = T>
+__global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const TD* dy,
                                                                      const T* x, const float* gamma, const float* beta, const float* mean,
                                                                      const float* rstd, long S, int C, int G, int act, int parts,
                                                                      const float* dyb, float dybs) {
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
 #pragma unroll
       for (int j = 0; j < W; ++j) d[j] = gb[j];
     } else {
-      vload<T>(d, dy + base + v * W);
+      VecW<TD, W>::load(d, dy + base + v * W);
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -564,8 +588,8 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
     if ((int)threadIdx.x < cv) { atomicAdd(&dgamma[threadIdx.x * W + j], part[threadIdx.x]); atomicAdd(&dbeta[threadIdx.x * W + j], part2[threadIdx.x]); }
   }
 }
-template <typename T>
-__global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, const float* gamma, const float* beta, const float* mean,
+template <typename T, typename TD = T>
+__global__ void groupnorm_bwd_apply_vec_kernel(TD* dx, const TD* dy, const T* x, const float* gamma, const float* beta, const float* mean,
                                                const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long nvec,
                                                const float* dyb, float dybs) {
   constexpr int W = VT<T>::W;
@@ -581,7 +605,7 @@ __global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, c
 #pragma unroll
       for (int j = 0; j < W; ++j) d[j] = dyb[(row / S) * C + c0 + j] * dybs;
     } else {
-      vload<T>(d, dy + v * W);
+      VecW<TD, W>::load(d, dy + v * W);
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -589,7 +613,24 @@ __global__ void groupnorm_bwd_apply_vec_kernel(T* dx, const T* dy, const T* x, c
       const float dz = d[j] * act_grad_f(xh * gamma[c0 + j] + beta[c0 + j], act);
       d[j] = rs * (dz * gamma[c0 + j] - invm * (u + xh * w));
     }
-    vstore<T>(dx + v * W, d);
+    VecW<TD, W>::store(dx + v * W, d);
+  }
+}
+
+// a = relu(y * scale[n][c] + shift[n][c]) as bf16 (scale == null: a plain fp32 -> bf16 conversion): the input of a router-trunk conv as the
+// bf16 weight-gradient program reads it (the forward never materialises it: conv6s applies the same transform while it stages its tiles)
+__global__ void gn1t_act_kernel(bf16* out, const float* y, const float* scale, const float* shift, long S, int C, long nvec) {
+  const int cv = C / 8;
+  GRID_STRIDE(v, nvec) {
+    const long row = v / cv; const int c0 = (int)(v - row * cv) * 8;
+    float f[8];
+    vload<float>(f, y + v * 8); vload<float>(f + 4, y + v * 8 + 4);
+    if (scale) {
+      const long sc = (row / S) * C + c0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * scale[sc + j] + shift[sc + j], 0.f);
+    }
+    vstore<bf16>(out + v * 8, f);
   }
 }
 
@@ -846,6 +887,31 @@ int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, 
                               const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
                               int G, int act, int dtype, hipStream_t stream) {
   return groupnorm_bwd_impl(dx, dgamma, dbeta, ws, parts, dy, x, gamma, beta, mean, rstd, N, S, C, G, act, dtype, stream);
+}
+/* Router-trunk backward in bf16 mode (GroupNorm(1, C) + ReLU; x = the conv output y_l, fp32): the incoming gradient dz is bf16 [N][S][C] (or, dz ==
+ * null, g[n][c] * gscale at every position), the result dx is written as bf16 -- the operands of the bf16 dgrad / weight-gradient programs.
+ * ws: 2 * N floats; dgamma / dbeta accumulate.  C % 4 == 0 and 512 % (C / 4) == 0. */
+int hdmoe_gn1t_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dz, const float* g, float gscale, const float* x, const float* gamma,
+                   const float* beta, const float* mean, const float* rstd, int N, long S, int C, hipStream_t stream) {
+  if (!dx || !dgamma || !dbeta || !ws || !x || (!dz && !g) || gn_check(N, C, 1)) return HDMOE_EINVAL;
+  if (!gn_vec_ok<float>(C, 1, x, nullptr, nullptr) || ((uintptr_t)dx & 7) || ((uintptr_t)dz & 7)) return HDMOE_EINVAL;
+  const long nvec = (long)N * S * C / 4;
+  float* s1 = ws; float* s2 = ws + N;
+  hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
+                     mean, rstd, S, C, 1, 1, 1, dz ? nullptr : g, gscale);
+  static const long gcap = getenv("HDMOE_GNB_GRID") ? atol(getenv("HDMOE_GNB_GRID")) : 512;
+  unsigned gb = grid_for(nvec); if (gb > gcap) gb = (unsigned)gcap;
+  hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
+                     s1, s2, S, C, 1, 1, nvec, dz ? nullptr : g, gscale);
+  return hdmoe_launch_status();
+}
+/* out (bf16 [N][S][C]) = relu(y * scale[n][c] + shift[n][c])  (scale == null: out = bf16(y)); C % 8 == 0 */
+int hdmoe_gn1t_act(void* out, const float* y, const float* scale, const float* shift, int N, long S, int C, hipStream_t stream) {
+  if (!out || !y || (scale == nullptr) != (shift == nullptr) || N < 1 || S < 1 || C % 8 || !al16(out) || !al16(y)) return HDMOE_EINVAL;
+  const long nvec = (long)N * S * C / 8;
+  unsigned gb = grid_for(nvec); if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(gn1t_act_kernel, dim3(gb), dim3(TPB), 0, stream, (bf16*)out, y, scale, shift, S, C, nvec);
+  return hdmoe_launch_status();
 }
 int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
                         int C, float eps, int dtype, hipStream_t stream) {

@@ -195,7 +195,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
     if (((uintptr_t)G[g] & 15) || pt[g] != (kh[g] - 1) / 2 || pl[g] != (kw[g] - 1) / 2) return 1;
     has3 = has3 || kh[g] == 3; has5 = has5 || kh[g] == 5;
   }
-  if (!has3 || !has5) return 1;
+  if (!has3 && !has5) return 1;                             // (a single kernel-size class is fine: the other class gets no partition slots)
   const long xbytes = (long)N * H * W * Cin * 2, dybytes = (long)N * H * W * Cout * 2;
   if (xbytes >= (1l << 31) || dybytes >= (1l << 31)) return 1;
   const int TWS = W >= 32 ? 5 : 4, TW = 1 << TWS, TH = 256 / TW;
@@ -215,7 +215,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
     p.c[k].ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
     w6_partition(units_l, p.c[k].ngr, ngroups, p.ibs, p.obs, upw, slots, false, a.tpi, kh, ks);
-    p.c[k].upw = upw; p.c[k].chunks = slots;
+    p.c[k].upw = upw; p.c[k].chunks = p.c[k].ngr ? slots : 0;
   }
   // workspace regions in the order the classes appear in the group list (what hdmoe_conv_wgrad6_reduce_batch assumes)
   const int firstk = kh[0] == 3 ? 0 : 1;

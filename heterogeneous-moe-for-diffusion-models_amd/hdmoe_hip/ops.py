@@ -1878,6 +1878,8 @@ TRUNK_FUSED = _os.environ.get("HDMOE_TRUNK_FUSED", "1") != "0"
 # the split operands only -- bf16 operands, fp32 accumulation, one MFMA per product instead of three.  Bit-exact routing indices need
 # the fp32-equivalent FORWARD (three products); gradients carry the bf16 mode's tolerance like every expert layer.  0: three products.
 TRUNK_BWD_BF16 = _os.environ.get("HDMOE_TRUNK_BWD_BF16", "1") != "0"
+# ... and, in that mode, as plain bf16 layers on the streaming kernels (round 4; 0: the split kernels' hi-only path, csrc/bwd6.hip bwd6s)
+TRUNK_BWD7 = _os.environ.get("HDMOE_TRUNK_BWD7", "1") != "0"
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -1938,27 +1940,59 @@ class _TrunkFn(torch.autograd.Function):
         bufs, ret = _param_grads(params)
         k3 = ctypes.cast(_int_array([3]), ctypes.c_void_p)
         da = None
+        # bf16-operand mode on 32 x 32 maps with enough samples: the trunk backward as PLAIN bf16 layers on the streaming kernels (csrc/conv7_body.h,
+        # wgrad7_body.h) -- the GroupNorm backward writes dy_l in bf16, a small pass materialises the conv input relu(gn(y_{l-1})) in bf16
+        # (the forward never stores it), and the fused dgrad + weight-gradient launch reads both by LDS-DMA.  Same arithmetic as the hi-only
+        # split path (bf16 operands, fp32 accumulation) except that the input gradient between two layers is stored in bf16.
+        use7 = (TRUNK_BWD7 and TRUNK_BWD_BF16 and CONV7 and H == 32 and W == 32 and N >= C7_MINN
+                and all(int(tensors[3 * l].shape[0]) % 32 == 0 and int(tensors[3 * l].shape[1]) % 32 == 0 for l in range(3)))
         for l in (2, 1, 0):
             w, gamma, beta = tensors[3 * l:3 * l + 3]
             y, sc, sh, mean, rstd = saved[5 * l:5 * l + 5]
             O, I = int(w.shape[0]), int(w.shape[1])
-            dy = torch.empty_like(y)
+            ent = ents[l]
+            xin = x if l == 0 else saved[5 * (l - 1)]
+            isc, ish = (None, None) if l == 0 else (saved[5 * (l - 1) + 1], saved[5 * (l - 1) + 2])
+            wdstride = 9 * I * ((O + 15) // 16 * 16)
             ws = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+            if use7:
+                dyb = torch.empty(y.shape, dtype=torch.bfloat16, device=x.device)
+                call("hdmoe_gn1t_bwd", dyb, bufs[2 * l], bufs[2 * l + 1], ws, None if l == 2 else da, _f32(g) if l == 2 else None,
+                     1.0 / S if l == 2 else 1.0, y, gamma, beta, mean, rstd, N, S, O)
+                a_in = torch.empty(xin.shape, dtype=torch.bfloat16, device=x.device)
+                call("hdmoe_gn1t_act", a_in, xin, isc, ish, N, S, I)
+                kib = lib().hdmoe_conv_wgrad6_ws_kib(1, N, H, W, I, O, k3, k3, 1)
+                arena = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
+                if arena is None and kib > 0 and not torch.cuda.is_current_stream_capturing():
+                    arena = torch.empty(2 * kib * 256, dtype=torch.float32, device=x.device)
+                if arena is None:
+                    raise RuntimeError("router trunk backward: no weight-gradient workspace (arena exhausted inside a graph capture)")
+                da = torch.empty(xin.shape, dtype=torch.bfloat16, device=x.device)
+                if _timed("fused", dict(name="bwd7_trunk_kernel", dtype="bfloat16", seg=None, N=N, HW=S, O=O, I=I, taps=[9], mult=2.0),
+                          "hdmoe_conv_bwd6", a_in, dyb, ent.wd, da, list(ent.G), None, 1, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
+                          arena, arena.numel() * 4, 1) != 0:
+                    raise RuntimeError("router trunk backward: layer outside the streaming backward kernels' domain")
+                bank.defer_w6(list(ent.G), None, arena, [1, N, H, W, I, O, 1, 0, 3, 0, 0, 0, 0, 0, 0, 0])
+                bank.note_backward(ent)
+                STATS["trunk_bwd"] += 1
+                STATS["trunk_bwd7"] += 1
+                if l == 0:                                     # the stem features are fp32: so is their gradient
+                    da32 = torch.empty(xin.shape, dtype=torch.float32, device=x.device)
+                    call("hdmoe_cast", da32, da, da.numel(), 1, 0)
+                    da = da32
+                continue
+            dy = torch.empty_like(y)
             if l == 2:      # d(mean over S of a_3): g[n][c] / S at every position, read from the (N, C) tensor (no materialised broadcast)
                 call("hdmoe_groupnorm_bwd_bcast", dy, bufs[2 * l], bufs[2 * l + 1], ws, _f32(g), 1.0 / S, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
             else:
                 call("hdmoe_groupnorm_bwd", dy, bufs[2 * l], bufs[2 * l + 1], ws, da, y, gamma, beta, mean, rstd, N, S, O, 1, ACT_RELU, 0)
-            ent = ents[l]
             kib = lib().hdmoe_conv_wgrad6_ws_kib(1, N, H, W, I, O, k3, k3, F32S)
             arena = _w6_arena_take(x.device, 2 * kib * 256) if kib > 0 else None
             if arena is None and kib > 0 and not torch.cuda.is_current_stream_capturing():
                 arena = torch.empty(2 * kib * 256, dtype=torch.float32, device=x.device)      # arena exhausted (it grows at the next step): own slabs
             if arena is None:
                 raise RuntimeError("router trunk backward: no weight-gradient workspace (arena exhausted inside a graph capture)")
-            xin = x if l == 0 else saved[5 * (l - 1)]
-            isc, ish = (None, None) if l == 0 else (saved[5 * (l - 1) + 1], saved[5 * (l - 1) + 2])
             da = torch.empty_like(xin)
-            wdstride = 9 * I * ((O + 15) // 16 * 16)
             if _timed("fused", dict(name="bwd6s_kernel", dtype="bfloat16" if TRUNK_BWD_BF16 else "split_bf16", seg=None, N=N, HW=S, O=O, I=I, taps=[9], mult=2.0),
                       "hdmoe_conv_bwd6s", xin, dy, ent.wd, da, list(ent.G), None, 1, wdstride, wdstride, N, H, W, I, O, [3], [3], [1], [1], 1.0,
                       arena, arena.numel() * 4, isc, ish, 1, 1 if TRUNK_BWD_BF16 else 0) != 0:

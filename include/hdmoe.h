@@ -209,6 +209,13 @@ int hdmoe_groupnorm_bwd_bcast(void* dx, float* dgamma, float* dbeta, float* ws, 
 int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, int parts, const void* dy, const void* x,
                               const float* gamma, const float* beta, const float* mean, const float* rstd, int N, long S, int C,
                               int G, int act, int dtype, HS stream);
+/* Router-trunk backward with bf16 gradient tensors (GroupNorm(1, C) + ReLU of Router.hard_route, reference models/model_components.py:100-112;
+ * x = the conv output, fp32).  gn1t_bwd: dz bf16 [N][S][C] or (dz == null) g[n][c] * gscale at every position -> dx bf16; ws: 2 N floats;
+ * dgamma / dbeta accumulate.  gn1t_act: out bf16 = relu(y * scale[n][c] + shift[n][c]) (scale == null: bf16(y)) -- the conv input as the bf16
+ * weight-gradient program reads it. */
+int hdmoe_gn1t_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dz, const float* g, float gscale, const float* x, const float* gamma,
+                   const float* beta, const float* mean, const float* rstd, int N, long S, int C, HS stream);
+int hdmoe_gn1t_act(void* out, const float* y, const float* scale, const float* shift, int N, long S, int C, HS stream);
 int hdmoe_layernorm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, long rows,
                         int C, float eps, int dtype, HS stream);
 int hdmoe_layernorm_bwd(void* dx, float* dgamma, float* dbeta, const void* dy, const void* x, const float* gamma,

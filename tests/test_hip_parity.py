@@ -1311,7 +1311,7 @@ def test_multi_linear_matches_the_per_layer_path(G, R, I, Os, four_d):
 
 
 @pytest.mark.parametrize("bwd_bf16", [False, True])
-@pytest.mark.parametrize("N,H,C,k", [(5, 32, 32, 2), (3, 16, 32, 1), (9, 64, 32, 1)])
+@pytest.mark.parametrize("N,H,C,k", [(5, 32, 32, 2), (3, 16, 32, 1), (9, 64, 32, 1), (200, 32, 32, 2)])
 def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k, bwd_bf16):
     """Router.hard_route with GroupNorm(1, C) + ReLU folded into the neighbouring split-bf16 convs (ops.router_trunk: statistics from the
     conv epilogue, the affine + ReLU applied while the next conv / weight gradient stage the tensor, pooled read at the end) against the
@@ -1329,10 +1329,13 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k, bwd_bf16
         for nm in (r.hard_route[1], r.hard_route[4], r.hard_route[7]):
             nm.weight.uniform_(0.5, 1.5); nm.bias.uniform_(-0.3, 0.3)
     r.eval()
+    if N >= 192 and not bwd_bf16:
+        pytest.skip("the large batch is there for the streaming-kernel backward (bf16 operands, N >= 192)")
     x = torch.randn(N, C, H, H, device=DEV)
     te = torch.randn(N, 16, device=DEV)
     prev = hdmoe_hip.compute_dtype()
     prev_bwd = ops.TRUNK_BWD_BF16
+    ops.STATS.clear()
     hdmoe_hip.set_compute_dtype(torch.bfloat16)
     ops.TRUNK_BWD_BF16 = bwd_bf16
     grel = 2e-2 if bwd_bf16 else 2e-4
@@ -1354,6 +1357,8 @@ def test_fused_router_trunk_matches_the_layer_by_layer_path(N, H, C, k, bwd_bf16
         ops.TRUNK_BWD_BF16 = prev_bwd
         hdmoe_hip.set_compute_dtype(prev)
     assert all(e.ready for e in r._hdmoe_bank.entries.values())
+    if N >= 192 and H == 32:                                       # the trunk backward ran as bf16 layers on the streaming kernels (csrc/conv7_body.h, wgrad7_body.h)
+        assert ops.STATS["trunk_bwd7"] >= 3, dict(ops.STATS)
     (l0, dx0, pg0), (l1, dx1, pg1), (l2, _, _) = res["layers"], res["fused"], res["fused_sub"]
     close_scaled(l1, l0, 2e-5, msg="logits")
     assert torch.equal(torch.topk(l1, k, dim=-1).indices, torch.topk(l0, k, dim=-1).indices)
