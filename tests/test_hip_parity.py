@@ -1741,7 +1741,9 @@ def test_full_size_batch_independence_and_router_invariants(trunk_bwd_bf16):
         # backward sums a few terms with float atomics (1e-7 run-to-run): 1e-5 with the three-product trunk backward.  With bf16 operands
         # in the trunk backward (ops.TRUNK_BWD_BF16, the default of this mode) such a perturbation becomes a one-ulp bf16 change
         # (4e-3 relative) of the odd operand element: measured 1e-5 ... 7e-5 of the tensor's maximum from run to run
-        close_scaled(gfull, torch.cat([g1, g2]), 3e-4 if trunk_bwd_bf16 else 1e-5, msg="x.grad")
+        # (round 4: the full batch -- N = 256 >= 192 samples -- runs the trunk backward as bf16 layers on the streaming kernels and stores the
+        #  input gradient between two trunk layers in bf16, the 128-sample halves take the split kernels with an fp32 one: measured 4.6e-4)
+        close_scaled(gfull, torch.cat([g1, g2]), 1.5e-3 if trunk_bwd_bf16 else 1e-5, msg="x.grad")
         for key, mask in (("Unet_raw", um), ("vit_raw", vm)):
             logits = full[key].detach().float()
             assert bool(((logits == float("-inf")) == (mask == 0)).all()), key          # masked experts: -inf logits
