@@ -432,7 +432,7 @@ def main():
         buckets.enabled = True
         if graphed is not None:
             if hasattr(graphed, "after") and multi and os.environ.get("HDMOE_BENCH_NO_AFTER", "0") != "1":          # staged step: a branch's bucket goes to RCCL as soon as its backward is launched
-                graphed.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
+                graphed.after = buckets.staged_hooks(graphed)
 
             def step():
                 l = graphed()
@@ -480,6 +480,17 @@ def main():
         torch.cuda.synchronize()
         stage_ms = graphed.stage_times()
         graphed.timing = False
+    # when does each gradient bucket become final (= its backward section ends) relative to the U-Net bank's backward?  (the hooks hand a bucket
+    # to the process group right behind the launch of its section: the collective starts when the section's stream gets there)
+    grad_buckets = None
+    if stage_ms and "unet_bwd0" in stage_ms:
+        sec_of = {"unet_s3": "unet_bwd", "unet_s2": "unet_bwd2", "unet_s1": "unet_bwd1", "vit": "vit_bwd", "unet_s0": "unet_bwd0", "rest": "pre_bwd"}
+        u0, u1 = stage_ms["unet_bwd"][0], stage_ms["unet_bwd0"][1]
+        tot = float(buckets.nbytes())
+        grad_buckets = {t: dict(bytes=4 * b.numel(), final_at_ms=stage_ms[sec_of[t]][1],
+                                frac_of_unet_bwd=round((stage_ms[sec_of[t]][1] - u0) / max(u1 - u0, 1e-9), 3)) for t, b in zip(buckets.tags, buckets.buckets)}
+        early = sum(v["bytes"] for v in grad_buckets.values() if v["frac_of_unet_bwd"] <= 0.75)
+        grad_buckets["_bytes_final_before_75pct_of_unet_bwd"] = round(early / tot, 3)
     mem_growth = torch.cuda.memory_allocated() - mem0
     gc.enable()
     grads_equal = None
@@ -632,7 +643,8 @@ def main():
                        + (" + RCCL grad all-reduce" if multi else ""), "launch": launch_desc, "stage_ms": stage_ms, "optimizer": "excluded (metric is fwd+bwd)",
                        "router_dtype": "f32 tensors; forward split-bf16 = fp32-equivalent (routing indices bit-exact), backward bf16 operands + fp32 accumulation", "loss": round(loss_val, 5), "loss_ok": loss_ok, "grads_equal_across_ranks": grads_equal, "hbm_growth_bytes_over_timed_region": mem_growth, "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
                        "masks": "all-ones (timed value); MaskGenerator(step=0, BW=0.3) leg: "
-                                + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes()},
+                                + (f"{ms_masked:.3f} ms/step" if ms_masked is not None else "n/a"), "grad_bytes": buckets.nbytes(),
+                       "grad_buckets": grad_buckets},
             "roofline": roof, "roofline_expert": getattr(roofline_leg, "expert", None), "attention": attention_rep, "cpu_baseline": cpu,
             "sampler": sampler_rec,
         }

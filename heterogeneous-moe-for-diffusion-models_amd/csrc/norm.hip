@@ -528,14 +528,18 @@ template <> struct VecW<bf16, 4> {
     *reinterpret_cast<bf16x4*>(p) = v;
   }
 };
-template <typename T, typename TD = T>
+template <> struct VecW<float, 8> {                          // two 16-byte accesses
+  static DEVI void load(float* f, const float* p) { vload<float>(f, p); vload<float>(f + 4, p + 4); }
+  static DEVI void store(float* p, const float* f) { vstore<float>(p, f); vstore<float>(p + 4, f + 4); }
+};
+template <typename T, typename TD = T, int WV = VT<T>::W>
 __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1, float* s2, float* dgamma, float* dbeta, const TD* dy,
                                                                      const T* x, const float* gamma, const float* beta, const float* mean,
                                                                      const float* rstd, long S, int C, int G, int act, int parts,
                                                                      const float* dyb, float dybs) {
   // dyb (or null): the incoming gradient is dyb[n][c] * dybs at every position (the backward of a mean over the positions) -- read from
   // the (N, C) tensor instead of a materialised broadcast
-  constexpr int W = VT<T>::W;
+  constexpr int W = WV;
   __shared__ float part[512], part2[512];
   const int n = blockIdx.x, Cg = C / G, cv = C / W;
   // parts > 1 (small batches): blockIdx.y owns a row range and adds its sums into the pre-zeroed s1 / s2
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
   for (int j = 0; j < W; ++j) gb[j] = dyb ? dyb[(long)n * C + mych + j] * dybs : 0.f;
   for (long v = threadIdx.x; v < nv; v += blockDim.x) {
     float f[W], d[W];
-    vload<T>(f, x + base + v * W);
+    VecW<T, W>::load(f, x + base + v * W);
     if (dyb) {
 #pragma unroll
       for (int j = 0; j < W; ++j) d[j] = gb[j];
@@ -588,11 +592,11 @@ __global__ __launch_bounds__(512) void groupnorm_bwd_stats_vec_kernel(float* s1,
     if ((int)threadIdx.x < cv) { atomicAdd(&dgamma[threadIdx.x * W + j], part[threadIdx.x]); atomicAdd(&dbeta[threadIdx.x * W + j], part2[threadIdx.x]); }
   }
 }
-template <typename T, typename TD = T>
+template <typename T, typename TD = T, int WV = VT<T>::W>
 __global__ void groupnorm_bwd_apply_vec_kernel(TD* dx, const TD* dy, const T* x, const float* gamma, const float* beta, const float* mean,
                                                const float* rstd, const float* s1, const float* s2, long S, int C, int G, int act, long nvec,
                                                const float* dyb, float dybs) {
-  constexpr int W = VT<T>::W;
+  constexpr int W = WV;
   const int Cg = C / G, cv = C / W;
   const float invm = 1.f / (float)(S * Cg);
   GRID_STRIDE(v, nvec) {
@@ -600,7 +604,7 @@ __global__ void groupnorm_bwd_apply_vec_kernel(TD* dx, const TD* dy, const T* x,
     const long sg = (row / S) * G + c0 / Cg;
     const float m = mean[sg], rs = rstd[sg], u = s1[sg], w = s2[sg];
     float f[W], d[W];
-    vload<T>(f, x + v * W);
+    VecW<T, W>::load(f, x + v * W);
     if (dyb) {
 #pragma unroll
       for (int j = 0; j < W; ++j) d[j] = dyb[(row / S) * C + c0 + j] * dybs;
@@ -894,14 +898,15 @@ int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, 
 int hdmoe_gn1t_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dz, const float* g, float gscale, const float* x, const float* gamma,
                    const float* beta, const float* mean, const float* rstd, int N, long S, int C, hipStream_t stream) {
   if (!dx || !dgamma || !dbeta || !ws || !x || (!dz && !g) || gn_check(N, C, 1)) return HDMOE_EINVAL;
-  if (!gn_vec_ok<float>(C, 1, x, nullptr, nullptr) || ((uintptr_t)dx & 7) || ((uintptr_t)dz & 7)) return HDMOE_EINVAL;
-  const long nvec = (long)N * S * C / 4;
+  // 8 channels per thread: 16-byte accesses to the bf16 tensors, two per fp32 vector
+  if (C % 8 || C / 8 > 512 || 512 % (C / 8) || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)dz & 15)) return HDMOE_EINVAL;
+  const long nvec = (long)N * S * C / 8;
   float* s1 = ws; float* s2 = ws + N;
-  hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
+  hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16, 8>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
                      mean, rstd, S, C, 1, 1, 1, dz ? nullptr : g, gscale);
   static const long gcap = getenv("HDMOE_GNB_GRID") ? atol(getenv("HDMOE_GNB_GRID")) : 512;
   unsigned gb = grid_for(nvec); if (gb > gcap) gb = (unsigned)gcap;
-  hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
+  hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16, 8>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
                      s1, s2, S, C, 1, 1, nvec, dz ? nullptr : g, gscale);
   return hdmoe_launch_status();
 }

@@ -9,10 +9,14 @@ When do the collectives go out?  Almost every gradient of this path is written s
 weight bank's finish launch, the norm / bias / table backward kernels) and never passes through an AccumulateGrad node, so
 autograd hooks cannot tell when a bucket is complete.  Completion is known structurally instead:
   * default (multi-stream step): the parameters are bucketed by the SECTION of the staged step (hdmoe_hip/graph.py) whose backward
-    finishes them -- "vit" (ViT router + experts), "unet" (U-Net router + experts), "rest" (stem, fusion, head, preconditioning).
-    ``launch_tag("vit")`` / ``launch_tag("unet")`` are called by StagedStep right after the section's backward graph has been
-    launched, on that section's stream: the all-reduce then runs beside the remaining sections.  ``finish()`` sends what is left
-    and waits.  Without a StagedStep everything goes out from ``finish()`` (correct, not overlapped).
+    finishes them, in the order the sections complete: the U-Net bank's backward runs as four sections (graph.Stager.SPLIT_UNET_BWD) --
+    "unet_s3" (full-resolution decoder entries + output conv), "unet_s2" (decoder below), "unet_s1" (encoder below), then "vit" (ViT
+    router + experts), "unet_s0" (full-resolution encoder entries, the embedding layers of every block, the U-Net router) and "rest" (stem,
+    fusion, head, preconditioning).  ``staged_hooks(staged)`` gives StagedStep one hook per section; each runs right after that section's
+    backward graph has been launched, on that section's stream, and hands ITS bucket to the process group: the all-reduce of the decoder
+    gradients (two thirds of the U-Net experts' parameters) runs beside the encoder sections.  RCCL executes a group's collectives in
+    issue order, hence buckets ordered by completion.  ``finish()`` sends what is left and waits.  Without a StagedStep everything goes out
+    from ``finish()`` (correct, not overlapped).
   * HDMOE_SIDE_STREAMS=0 (one stream): 16 MB buckets in reverse registration order; hooks launch the complete prefix for the few
     gradients that do come through autograd, the rest again from ``finish()``.
 The order of collectives is the same on every rank by construction (tags in a fixed order / bucket index order).
@@ -26,15 +30,27 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    TAGS = ("vit", "unet", "rest")
+    TAGS = ("unet_s3", "unet_s2", "unet_s1", "vit", "unet_s0", "rest")     # completion order of the staged backward
 
     @staticmethod
-    def tag_of(name: str) -> str:
-        """Section of the staged step that completes the parameter's gradient (HDMOEM attribute names, models/_assembly.py)."""
-        if ".vit_router." in "." + name or ".VIT_experts." in "." + name:
+    def tag_of(name: str, top: str = "") -> str:
+        """Section of the staged step that completes the parameter's gradient (HDMOEM attribute names, models/_assembly.py; ``top`` = the
+        full-resolution level prefix of the U-Net experts, e.g. "32x32")."""
+        n = "." + name
+        if ".vit_router." in n or ".VIT_experts." in n:
             return "vit"
-        if ".Unet_router." in "." + name or ".Unet_experts." in "." + name:
-            return "unet"
+        if ".Unet_router." in n:
+            return "unet_s0"                                       # (its backward runs beside the bank's, on a third stream: last U-Net bucket)
+        if ".Unet_experts." in n:
+            if ".emb_layer." in n or ".map_noise." in n or ".map_text." in n:
+                return "unet_s0"                                   # one multi-tensor backward for all blocks' embedding layers, in the last section
+            if ".decoders." in n:
+                return "unet_s3" if top and f".decoders.{top}_" in n else "unet_s2"
+            if ".out_conv." in n or n.endswith(".out_gain"):
+                return "unet_s3"
+            if ".encoders." in n:
+                return "unet_s0" if (not top or f".encoders.{top}_" in n) else "unet_s1"
+            return "unet_s0"
         return "rest"
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, force_collectives: bool = False):
@@ -49,10 +65,16 @@ class GradBuckets:
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
         self.tags: List[str] = []
+        top = ""
+        for name, mod in module.named_modules():
+            if name.endswith("Unet_experts.0") and hasattr(mod, "encoders") and len(mod.encoders):
+                top = next(iter(mod.encoders.keys())).split("_")[0]
+                break
+        self.top = top
         if _ops.SIDE_STREAMS:
             # one flat bucket per section of the staged step (sections complete as a whole: see the module docstring)
             for tag in self.TAGS:
-                members = [p for n, p in named if self.tag_of(n) == tag]
+                members = [p for n, p in named if self.tag_of(n, top) == tag]
                 if members:
                     self._seal(members, sum(p.numel() for p in members))
                     self.tags.append(tag)
@@ -128,21 +150,27 @@ class GradBuckets:
             self._works[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def launch_tag(self, tag: str):
-        """The section ``tag`` of the staged step has been launched on the current stream: send its bucket.  Collectives are issued
-        strictly in bucket order on every rank, so an earlier bucket that is still waiting goes first (it is complete as well:
-        sections are launched in bucket order)."""
+        """The section ``tag`` of the staged step has been launched on the current stream: send its bucket (and only its bucket -- an earlier
+        bucket may belong to a section on another stream).  Every rank runs the same staged step, so the collectives are issued in the
+        same order everywhere."""
         if not self.enabled or tag not in self.tags:
             return
-        bi = self.tags.index(tag)
-        while self._next <= bi:
-            self._launch(self._next)
-            self._next += 1
+        self._launch(self.tags.index(tag))
+
+    def staged_hooks(self, staged) -> dict:
+        """{backward section of ``staged`` (hdmoe_hip.graph.StagedStep): hook}: each hook runs behind the launch of its section, on the
+        section's stream, and hands that section's gradient bucket to the process group."""
+        L = self.launch_tag
+        if len(getattr(staged, "unet_sub", [])) == 3:
+            return {"unet_bwd": lambda: L("unet_s3"), "unet_bwd2": lambda: L("unet_s2"), "unet_bwd1": lambda: L("unet_s1"),
+                    "vit_bwd": lambda: L("vit"), "unet_bwd0": lambda: L("unet_s0")}
+        # the U-Net bank's backward as ONE section: all of its buckets behind it
+        return {"vit_bwd": lambda: L("vit"), "unet_bwd": lambda: [L(t) for t in ("unet_s3", "unet_s2", "unet_s1", "unet_s0")]}
 
     def finish(self):
         """Call after backward: reduce every bucket that has not gone out yet, wait for all."""
-        while self._next < len(self.buckets):
-            self._launch(self._next)
-            self._next += 1
+        for bi in range(len(self.buckets)):                        # (_launch skips what a hook has already sent)
+            self._launch(bi)
         self._next = 0
         if self.usage is not None and (self.world > 1 or self.force):
             dist.all_reduce(self.usage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()

@@ -73,7 +73,12 @@ class Stager:
     ``graph.current()``: ``cut(stage, **tensors_by_producer_stage)`` at a boundary, ``backward(loss)`` instead of loss.backward()."""
 
     KIND = {"pre": "main", "ur": "r", "unet": "u", "vit": "v", "post": "main", "ucomb_bwd": "u", "ur_bwd": "r", "unet_bwd": "u", "vit_bwd": "v",
-            "pre_bwd": "main"}
+            "pre_bwd": "main", "unet_bwd2": "u", "unet_bwd1": "u", "unet_bwd0": "u"}
+    # SPLIT_UNET_BWD (round 4): the U-Net bank's backward as up to FOUR sections on its stream -- decoder at full resolution (+ output conv),
+    # decoder below, encoder below, encoder at full resolution (+ embeddings) -- cut with detached leaves inside the forward graph
+    # (models/model_components.py unet_expert_bank_forward).  Each section finishes its own weight gradients (bank.finish_stage), so its
+    # gradient bucket can go to RCCL while the later sections still run (hdmoe_hip/dp.py); single-process jobs just replay four graphs.
+    SPLIT_UNET_BWD = __import__("os").environ.get("HDMOE_SPLIT_UNET_BWD", "1") != "0"
     # SPLIT_ROUTER: the U-Net branch is the longer one, and its router's backward (2.2 ms of kernels) needs nothing from the bank's
     # backward but the gradient of the routing weights, which the bank's FIRST backward kernel (the combine) produces.  The router
     # therefore gets its own stream and graphs (`ur`, `ur_bwd`), and the combine backward its own small graph (`ucomb_bwd`) so that
@@ -127,7 +132,8 @@ class Stager:
         out = []
         for producer, tensors in by_producer.items():
             for t in tensors:
-                if torch.is_tensor(t) and t.requires_grad:
+                if torch.is_tensor(t) and t.requires_grad and not (t.is_leaf and producer.startswith("unet_c")):
+                    # (inside the U-Net bank a tensor that already IS a boundary leaf stays one: no chains of leaves)
                     d = t.detach().requires_grad_(True)
                     self.cuts[producer].append((t, d))
                     out.append(d)
@@ -155,9 +161,15 @@ class Stager:
             if "ur" in self.order:
                 self._section("ucomb_bwd", "ucomb")               # combine backward: gradients of the bank output rows and of the routing weights
                 self._section("unet_bwd", "unet")
+                for k in (2, 1, 0):                               # the bank's own sections, in backward order (SPLIT_UNET_BWD)
+                    if self.cuts.get(f"unet_c{k}"):
+                        self._section(f"unet_bwd{k}", f"unet_c{k}")
                 self._section("ur_bwd", "ur")
             else:
                 self._section("unet_bwd", "unet")
+                for k in (2, 1, 0):
+                    if self.cuts.get(f"unet_c{k}"):
+                        self._section(f"unet_bwd{k}", f"unet_c{k}")
             self._section("vit_bwd", "vit")
             self._section("pre_bwd", "pre")
         finally:
@@ -223,9 +235,11 @@ class StagedStep:
             cur.wait_stream(s)
         torch.cuda.synchronize(self.device)
         st = self._run(step_fn, capture=True)
-        if st.order not in (self.ORDER, self.ORDER_R):
+        core = [n for n in st.order if n not in ("unet_bwd2", "unet_bwd1", "unet_bwd0")]
+        if core not in (self.ORDER, self.ORDER_R):
             raise RuntimeError(f"staged step: unexpected stage sequence {st.order}")
-        self.split_router = st.order == self.ORDER_R
+        self.split_router = core == self.ORDER_R
+        self.unet_sub = [n for n in ("unet_bwd2", "unet_bwd1", "unet_bwd0") if n in st.order]    # further sections of the U-Net bank's backward
         self.graphs = st.graphs
         self._keep = st                                           # boundary tensors live in the graphs' pools
         self.after = {}                                           # {"unet_bwd" | "vit_bwd": callable}: run on that section's stream right after its launch
@@ -292,9 +306,21 @@ class StagedStep:
             run("unet_bwd", u)
             run("ur_bwd", r)
             run("vit_bwd", v)
-            done("vit_bwd", v)
-            u.wait_stream(r)                                      # the "unet" gradient bucket holds the router's parameters too
-            done("unet_bwd", u)
+            if self.unet_sub:
+                # the bank's sections one after the other on its stream; behind each the hook that hands its gradient bucket on
+                # (buckets are ordered by completion: decoder sections first, then the ViT branch, then what ends with the backward)
+                done("unet_bwd", u)
+                for name in self.unet_sub[:-1]:
+                    run(name, u)
+                    done(name, u)
+                run(self.unet_sub[-1], u)
+                done("vit_bwd", v)
+                u.wait_stream(r)                                  # the last U-Net bucket holds the router's parameters too
+                done(self.unet_sub[-1], u)
+            else:
+                done("vit_bwd", v)
+                u.wait_stream(r)                                  # the "unet" gradient bucket holds the router's parameters too
+                done("unet_bwd", u)
             main.wait_stream(u); main.wait_stream(v)
             run("pre_bwd", main)
             cur.wait_stream(main)
@@ -309,8 +335,17 @@ class StagedStep:
         u.wait_stream(main); v.wait_stream(main)
         run("unet_bwd", u)
         run("vit_bwd", v)
-        done("vit_bwd", v)
-        done("unet_bwd", u)
+        if self.unet_sub:
+            done("unet_bwd", u)
+            for name in self.unet_sub[:-1]:
+                run(name, u)
+                done(name, u)
+            run(self.unet_sub[-1], u)
+            done("vit_bwd", v)
+            done(self.unet_sub[-1], u)
+        else:
+            done("vit_bwd", v)
+            done("unet_bwd", u)
         main.wait_stream(u); main.wait_stream(v)
         run("pre_bwd", main)
         cur.wait_stream(main)

@@ -58,7 +58,7 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         xs = ops.gather_rows(x, plan)
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
-        ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg)
+        ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg, stager=stager)
         if stager is not None:
             (ys,) = stager.cut_local(unet=(ys,))
         return ops.combine_rows(ys, out_router, plan)

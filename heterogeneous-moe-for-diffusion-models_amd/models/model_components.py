@@ -196,9 +196,12 @@ class Unet_block(nn.Module):
 
 
 def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_emb: Tensor, text_emb: Optional[Tensor],
-                             seg: Optional[Tensor]) -> Tensor:
+                             seg: Optional[Tensor], stager=None) -> Tensor:
     """Unet_expert.forward (reference model_components.py:389-433) over a bank of experts.
-    x: (R,H,W,C) channel-last rows in expert-contiguous order; time_emb (R,T) / text_emb (R,text_dim) fp32."""
+    x: (R,H,W,C) channel-last rows in expert-contiguous order; time_emb (R,T) / text_emb (R,text_dim) fp32.
+    ``stager`` (staged step, hdmoe_hip/graph.py SPLIT_UNET_BWD): the autograd graph is cut with detached leaves behind the full-resolution
+    encoder entries, behind the encoder and in front of the full-resolution decoder entries, so that the backward runs as four sections
+    whose weight gradients are final -- and can be all-reduced -- one after the other."""
     e0 = experts[0]
     tr = e0.training
 
@@ -222,7 +225,24 @@ def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_e
         embs = list(ops.fanout(emb, len(blk)))                  # ONE gradient sum instead of nblk - 1 adds
     skips = []
     bi = 0
-    for name in e0.encoders.keys():
+    top = next(iter(e0.encoders.keys())).split("_")[0]          # "32x32": the full-resolution level
+    cut_on = stager is not None and getattr(stager, "SPLIT_UNET_BWD", False) and len(e0.block_channels) > 1
+
+    def cut(k):
+        # boundary k between two backward sections: everything alive here becomes a leaf (tensors that already are leaves stay)
+        nonlocal x, skips, films, embs
+        live = [x] + skips + [f for f in films[bi:] if f is not None] + [f for f in embs[bi:] if f is not None]
+        out = stager.cut_local(**{f"unet_c{k}": tuple(live)})
+        x, out = out[0], out[1:]
+        skips, out = list(out[:len(skips)]), out[len(skips):]
+        nf = sum(f is not None for f in films[bi:])
+        fl, el = iter(out[:nf]), iter(out[nf:])
+        films = films[:bi] + [None if f is None else next(fl) for f in films[bi:]]
+        embs = embs[:bi] + [None if f is None else next(el) for f in embs[bi:]]
+
+    films, embs = list(films), list(embs)
+    names = list(e0.encoders.keys())
+    for ni, name in enumerate(names):
         mods = [e.encoders[name] for e in experts]
         if "conv" in name:
             x = conv(mods, x, ones=True)                         # torch.cat([x, ones]) folded into the conv (:416)
@@ -231,8 +251,14 @@ def unet_expert_bank_forward(experts: Sequence["Unet_expert"], x: Tensor, time_e
             bi += 1
         x, sk = ops.fanout(x, 2)
         skips.append(sk)
+        if cut_on and name.startswith(top) and ni + 1 < len(names) and not names[ni + 1].startswith(top):
+            cut(0)                                               # behind the full-resolution encoder entries
+    if cut_on:
+        cut(1)                                                   # behind the encoder
     for name in e0.decoders.keys():
         mods = [e.decoders[name] for e in experts]
+        if cut_on and name == f"{top}_up":
+            cut(2)                                               # in front of the full-resolution decoder entries
         hx = None
         if "block" in name:
             if mods[0].resample == "keep":

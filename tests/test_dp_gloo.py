@@ -120,13 +120,22 @@ def _hdmoem_worker(rank, world, port, q, side_streams):
     names = [n for n, _ in model.named_parameters()]
     buckets = GradBuckets(model, bucket_mb=0.25)
     assert buckets.nbytes() == 4 * sum(p.numel() for p in model.parameters())
-    if side_streams:                                                 # one bucket per section of the staged step
-        assert buckets.tags == ["vit", "unet", "rest"] and not buckets.eager
+    if side_streams:                                                 # one bucket per section of the staged step, in completion order
+        assert buckets.tags == ["unet_s3", "unet_s2", "unet_s1", "vit", "unet_s0", "rest"] and not buckets.eager and buckets.top == "16x16"
         for tag, members in zip(buckets.tags, buckets._members):
             owned = {id(p) for p in members}
-            assert all((id(p) in owned) == (GradBuckets.tag_of(n) == tag) for n, p in model.named_parameters())
-        assert GradBuckets.tag_of("net.VIT_experts.0.patch.weight") == "vit" and GradBuckets.tag_of("net.Unet_router.linear.weights") == "unet"
-        assert GradBuckets.tag_of("net.input_proj.weights") == "rest" and GradBuckets.tag_of("log_var_linear.weights") == "rest"
+            assert all((id(p) in owned) == (GradBuckets.tag_of(n, buckets.top) == tag) for n, p in model.named_parameters())
+        T = lambda n: GradBuckets.tag_of(n, "16x16")
+        assert T("net.VIT_experts.0.patch.weight") == "vit" and T("net.Unet_router.linear.weights") == "unet_s0"
+        assert T("net.input_proj.weights") == "rest" and T("log_var_linear.weights") == "rest"
+        assert T("net.Unet_experts.1.decoders.16x16_block0.conv_res1.weights") == "unet_s3" and T("net.Unet_experts.1.out_conv.weights") == "unet_s3"
+        assert T("net.Unet_experts.1.out_gain") == "unet_s3" and T("net.Unet_experts.0.decoders.8x8_in0.conv_res1.weights") == "unet_s2"
+        assert T("net.Unet_experts.3.encoders.8x8_block0.conv_res2.weights") == "unet_s1" and T("net.Unet_experts.3.encoders.16x16_conv.weights") == "unet_s0"
+        assert T("net.Unet_experts.2.decoders.16x16_block0.emb_layer.weights") == "unet_s0" and T("net.Unet_experts.2.map_noise.weights") == "unet_s0"
+        # the decoder sections -- handed to the process group while the encoder sections still run -- hold most of the U-Net experts' bytes
+        nb = {t: sum(p.numel() for p in m) for t, m in zip(buckets.tags, buckets._members)}
+        unet_all = sum(v for t, v in nb.items() if t.startswith("unet"))
+        assert (nb["unet_s3"] + nb["unet_s2"]) > 0.55 * unet_all, nb
     else:
         assert len(buckets.buckets) >= 3 and buckets.eager
     # every parameter's .grad is a view into exactly one bucket, in reverse registration order
@@ -147,10 +156,10 @@ def _hdmoem_worker(rank, world, port, q, side_streams):
             p.grad.add_(mine[n])                                     # AccumulateGrad into the bucket view
             for h in (p._post_accumulate_grad_hooks or {}).values():  # what autograd calls after accumulating (hooks exist in the one-stream mode only)
                 h(p)
-        if side_streams:                                             # what StagedStep does after launching the two branch backwards
-            buckets.launch_tag("vit")
-            buckets.launch_tag("unet")
-            assert buckets._next == 2
+        if side_streams:                                             # what StagedStep's hooks do behind the backward sections, in its order
+            for tag in ("unet_s3", "unet_s2", "unet_s1", "vit", "unet_s0"):
+                buckets.launch_tag(tag)
+            assert sum(w is not None for w in buckets._works) == 5
         buckets.finish()
         # reference: average of both ranks' synthetic gradients
         for n, p in model.named_parameters():

@@ -80,12 +80,13 @@ def _worker(rank, world, port, q, backend="gloo", bf16=False):
 
     model = build()
     buckets = GradBuckets(model, force_collectives=world == 1)
-    assert buckets.tags == ["vit", "unet", "rest"]
+    assert buckets.tags == ["unet_s3", "unet_s2", "unet_s1", "vit", "unet_s0", "rest"]
     staged = hgraph.StagedStep(step_fn(model, inputs(rank), buckets.zero_grad), dev, warmup=2)
-    staged.after = {"vit_bwd": lambda: buckets.launch_tag("vit"), "unet_bwd": lambda: buckets.launch_tag("unet")}
+    assert staged.unet_sub == ["unet_bwd2", "unet_bwd1", "unet_bwd0"]     # the U-Net bank's backward runs as four sections
+    staged.after = buckets.staged_hooks(staged)
     for _ in range(2):
         staged()
-        assert buckets._next == 2                                  # the two branch buckets went out before finish()
+        assert sum(w is not None for w in buckets._works) == 5     # every branch bucket went out before finish()
         buckets.finish()
     torch.cuda.synchronize()
     bad = []
