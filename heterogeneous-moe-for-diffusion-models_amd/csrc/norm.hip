@@ -898,16 +898,25 @@ int hdmoe_groupnorm_bwd_split(void* dx, float* dgamma, float* dbeta, float* ws, 
 int hdmoe_gn1t_bwd(void* dx, float* dgamma, float* dbeta, float* ws, const void* dz, const float* g, float gscale, const float* x, const float* gamma,
                    const float* beta, const float* mean, const float* rstd, int N, long S, int C, hipStream_t stream) {
   if (!dx || !dgamma || !dbeta || !ws || !x || (!dz && !g) || gn_check(N, C, 1)) return HDMOE_EINVAL;
-  // 8 channels per thread: 16-byte accesses to the bf16 tensors, two per fp32 vector
-  if (C % 8 || C / 8 > 512 || 512 % (C / 8) || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)dz & 15)) return HDMOE_EINVAL;
-  const long nvec = (long)N * S * C / 8;
+  // 8 channels per thread (16-byte accesses to the bf16 tensors, two per fp32 vector) or 4 (HDMOE_GN1T_W=4: 8-byte bf16 accesses)
+  static const int wsel = getenv("HDMOE_GN1T_W") ? atoi(getenv("HDMOE_GN1T_W")) : 4;   // (measured: 171 vs 214 us for stats + apply at C = 128, 13.58 vs 13.93 ms/step)
+  const int Wv = (wsel == 4 || C % 8 || 512 % (C / 8)) ? 4 : 8;
+  if (C % Wv || C / Wv > 512 || 512 % (C / Wv) || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)dz & 15)) return HDMOE_EINVAL;
+  const long nvec = (long)N * S * C / Wv;
   float* s1 = ws; float* s2 = ws + N;
-  hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16, 8>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
-                     mean, rstd, S, C, 1, 1, 1, dz ? nullptr : g, gscale);
   static const long gcap = getenv("HDMOE_GNB_GRID") ? atol(getenv("HDMOE_GNB_GRID")) : 512;
   unsigned gb = grid_for(nvec); if (gb > gcap) gb = (unsigned)gcap;
-  hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16, 8>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
-                     s1, s2, S, C, 1, 1, nvec, dz ? nullptr : g, gscale);
+  if (Wv == 8) {
+    hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16, 8>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
+                       mean, rstd, S, C, 1, 1, 1, dz ? nullptr : g, gscale);
+    hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16, 8>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
+                       s1, s2, S, C, 1, 1, nvec, dz ? nullptr : g, gscale);
+  } else {
+    hipLaunchKernelGGL((groupnorm_bwd_stats_vec_kernel<float, bf16, 4>), dim3(N, 1), dim3(512), 0, stream, s1, s2, dgamma, dbeta, (const bf16*)dz, x, gamma, beta,
+                       mean, rstd, S, C, 1, 1, 1, dz ? nullptr : g, gscale);
+    hipLaunchKernelGGL((groupnorm_bwd_apply_vec_kernel<float, bf16, 4>), dim3(gb), dim3(TPB), 0, stream, (bf16*)dx, (const bf16*)dz, x, gamma, beta, mean, rstd,
+                       s1, s2, S, C, 1, 1, nvec, dz ? nullptr : g, gscale);
+  }
   return hdmoe_launch_status();
 }
 /* out (bf16 [N][S][C]) = relu(y * scale[n][c] + shift[n][c])  (scale == null: out = bf16(y)); C % 8 == 0 */
