@@ -71,6 +71,10 @@ class GradBuckets:
                 top = next(iter(mod.encoders.keys())).split("_")[0]
                 break
         self.top = top
+        # ONE allocation behind all buckets (16-byte aligned slices): zero_grad is a single fill, whatever the number of buckets
+        total = sum((p.numel() + 3) // 4 * 4 for _, p in named) + 4 * (len(self.TAGS) + len(named) // 1 * 0)
+        self._master = torch.zeros(total, dtype=torch.float32, device=named[0][1].device) if named else None
+        self._moff = 0
         if _ops.SIDE_STREAMS:
             # one flat bucket per section of the staged step (sections complete as a whole: see the module docstring)
             for tag in self.TAGS:
@@ -118,8 +122,13 @@ class GradBuckets:
                     p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
     def _seal(self, members, n):
-        p0 = members[0]
-        flat = torch.zeros(n, dtype=torch.float32, device=p0.device)
+        start = (self._moff + 3) // 4 * 4
+        if self._master is not None and start + n <= self._master.numel():
+            flat = self._master[start:start + n]
+            self._moff = start + n
+        else:                                                      # (cannot happen with the sizing above; keeps the class usable if it ever does)
+            flat = torch.zeros(n, dtype=torch.float32, device=members[0].device)
+            self._master = None
         off = 0
         for p in members:
             p.grad = flat[off:off + p.numel()].view_as(p)           # gradient_as_bucket_view
@@ -183,6 +192,9 @@ class GradBuckets:
             self._pending[bi] = 0
 
     def zero_grad(self):
+        if self._master is not None:
+            self._master.zero_()
+            return
         for flat in self.buckets:
             flat.zero_()
 
