@@ -480,6 +480,9 @@ def main():
         torch.cuda.synchronize()
         stage_ms = graphed.stage_times()
         graphed.timing = False
+        if getattr(graphed, "host_us", None):                # development (HDMOE_HOST_TIMES=1): host time of each graph launch, per call
+            hu = graphed.host_us
+            print("host us per graph launch: " + ", ".join(f"{k}={hu[k] / hu['_calls_' + k]:.0f}" for k in hu if not k.startswith("_")), file=sys.stderr, flush=True)
     # when does each gradient bucket become final (= its backward section ends) relative to the U-Net bank's backward?  (the hooks hand a bucket
     # to the process group right behind the launch of its section: the collective starts when the section's stream gets there)
     grad_buckets = None

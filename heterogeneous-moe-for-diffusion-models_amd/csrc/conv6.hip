@@ -32,6 +32,7 @@ __global__ __launch_bounds__(64 * C6_NW) void conv6_bf16_kernel(C6Args a) {
 static void* g_c6_stamps = nullptr;
 // development hook (tools/conv6_check.py --stamps): 8 x 64 u64 device buffer receiving workgroup 0's in-kernel time stamps
 extern "C" int hdmoe_conv6_debug_stamps(void* buf) { g_c6_stamps = buf; return HDMOE_OK; }
+void* hdmoe_debug_stamp_buffer() { return g_c6_stamps; }      // (shared with conv7.hip)
 
 // Launch geometry of conv6 for one layer (shared with the fused backward launch of bwd6.hip).  0 = planned, 1 = outside the domain.
 int conv6_plan(const ConvArgs& c, int dtype, C6Plan& plan) {

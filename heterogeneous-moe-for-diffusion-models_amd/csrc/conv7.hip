@@ -42,6 +42,7 @@ int conv7_plan(const ConvArgs& c, int dtype, C7Plan& plan) {
   a.xbytes = (int)xbytes; a.wbytes = (int)wbytes;
   static const int dbg = getenv("HDMOE_C7_DBG") ? atoi(getenv("HDMOE_C7_DBG")) : 0;
   a.dbg = dbg;
+  a.stamps = (unsigned long long*)hdmoe_debug_stamp_buffer();
   for (int g = 0; g < HDMOE_MAX_GROUPS; ++g) { a.ks[g] = c.kh[g]; a.order[g] = g; }
   for (int i = 1; i < c.ngroups; ++i)                       // groups by descending kernel size (heaviest images first)
     for (int k = i; k > 0 && a.ks[a.order[k]] > a.ks[a.order[k - 1]]; --k) { const int t = a.order[k]; a.order[k] = a.order[k - 1]; a.order[k - 1] = t; }

@@ -31,6 +31,7 @@ struct C7Args {
   float alpha, beta;
   int xbytes, wbytes;
   int dbg;                             // development ablations: 1 skip the MFMAs, 2 skip the tile DMA of later units, 4 skip the stores
+  unsigned long long* stamps;          // development: s_memtime stamps of workgroup 0 ([wave][64] slots; hdmoe_conv6_debug_stamps), or null
 };
 
 // Tile geometry.  32 x 32 maps: a tile is one image, [32 rows][35 pixel slots][64 B] (32 pixels + 3 pad slots shared with the next row), wave w
@@ -83,30 +84,40 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
   const int CI = a.Cin >> 5;
   const int cin2 = a.Cin * 2;
+  int nstamp = 0;
+  auto stamp = [&](int tag) {
+    if (a.stamps && bid == 0 && lane == 0 && nstamp < 63) {
+      a.stamps[wave * 64 + nstamp] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull);
+      ++nstamp;
+    }
+  };
+  stamp(1);
 
   // ---- unit list: images (pairs of images on 16 x 16 maps) of the groups in descending kernel size, dealt in a snake over the workgroups
-  int cum[HDMOE_MAX_GROUPS + 1];
+  int cum[HDMOE_MAX_GROUPS + 1], sbeg[HDMOE_MAX_GROUPS], send[HDMOE_MAX_GROUPS];   // (registers: unit_at touches no memory)
   cum[0] = 0;
 #pragma unroll
   for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) {
     int cnt = 0;
-    if (i < a.ngroups) { const int g = a.order[i]; cnt = a.seg ? a.seg[g + 1] - a.seg[g] : a.N; }
+    sbeg[i] = 0; send[i] = 0;
+    if (i < a.ngroups) {
+      const int g = a.order[i];
+      sbeg[i] = a.seg ? a.seg[g] : 0; send[i] = a.seg ? a.seg[g + 1] : a.N;
+      cnt = send[i] - sbeg[i];
+    }
     cum[i + 1] = cum[i] + (W16 ? (cnt + 1) >> 1 : cnt);
   }
   const int total = cum[HDMOE_MAX_GROUPS];
   auto unit_at = [&](int q, C7Unit& u) -> bool {
     const int pos = q * G + ((q & 1) ? G - 1 - bid : bid);
     if (pos >= total) return false;
-    int slot = 0;
+    int base = 0, g = a.order[0], s0 = sbeg[0], s1 = send[0];
 #pragma unroll
-    for (int i = 1; i < HDMOE_MAX_GROUPS; ++i) slot += (i < a.ngroups && pos >= cum[i]) ? 1 : 0;
-    int base = 0, g = 0;
-#pragma unroll
-    for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == slot) { base = cum[i]; g = a.order[i]; }
+    for (int i = 1; i < HDMOE_MAX_GROUPS; ++i)
+      if (i < a.ngroups && pos >= cum[i]) { base = cum[i]; g = a.order[i]; s0 = sbeg[i]; s1 = send[i]; }
     int ks = 3;
 #pragma unroll
     for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == g) ks = a.ks[i];
-    const int s0 = a.seg ? a.seg[g] : 0, s1 = a.seg ? a.seg[g + 1] : a.N;
     u.g = g; u.ks = ks;
     if (W16) { u.n = s0 + 2 * (pos - base); u.n2 = u.n + 1 < s1 ? u.n + 1 : -1; }
     else { u.n = s0 + pos - base; u.n2 = -1; }
@@ -208,8 +219,10 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
         // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free.
         //      vmcnt counts in issue order: what may stay in flight is whatever this wave issued AFTER the pieces it needs now
         if (s == 0) {
+          stamp(2);
           if (c == 0 && !first) c7_wait_barrier<NSTORE>();      // the previous block's / unit's epilogue stores
           else c7_wait_barrier<0>();
+          stamp(3);
         } else if (s == 1 && tile_next) {
           c7_wait_barrier<PPW>();                               // the tile pieces issued behind this stage's weight pieces
         } else {
@@ -261,6 +274,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
       if (!same_tile) tp ^= 1;
     }
     const int cobase = blk * 32 * CO;
+    stamp(4);
     // ---- epilogue: y = alpha * acc + beta * res, 16-byte stores (register quads paired across the half-waves)
     if (!(a.dbg & 4)) {
       bf16* Y = (bf16*)a.y;
@@ -300,6 +314,7 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
 #pragma unroll
         for (int b = 0; b < CO; ++b) asm volatile("" :: "v"(acc[m][b]));
     }
+    stamp(5);
     first = false;
     }                                                           // output blocks
   };

@@ -34,6 +34,7 @@ struct ConvFuse {
 // (the caller then takes the general kernels).
 int conv6_try_launch(const ConvArgs& a, const ConvFuse* fuse, int dtype, hipStream_t stream);
 
+void* hdmoe_debug_stamp_buffer();     // development: the buffer registered with hdmoe_conv6_debug_stamps (conv6.hip), or null
 // Whole-image streaming kernel for 32 x 32 maps (conv7.hip).  Same return convention.
 int conv7_try_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

@@ -7,6 +7,9 @@ path is sync-free and allocation goes through torch's caching allocator, so the 
 """
 from __future__ import annotations
 
+import os
+import time
+
 import torch
 
 from . import bank, ops
@@ -243,6 +246,7 @@ class StagedStep:
         self.graphs = st.graphs
         self._keep = st                                           # boundary tensors live in the graphs' pools
         self.after = {}                                           # {"unet_bwd" | "vit_bwd": callable}: run on that section's stream right after its launch
+        self.host_us = {} if os.environ.get("HDMOE_HOST_TIMES") == "1" else None
 
     def _run(self, step_fn, capture: bool):
         global _ACTIVE
@@ -278,7 +282,13 @@ class StagedStep:
                 if ev is not None:
                     ev[name] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[name][0].record(stream)
-                g[name].replay()
+                if self.host_us is None:
+                    g[name].replay()
+                else:                                             # development: host time of the graph launch itself (HDMOE_HOST_TIMES=1)
+                    t0 = time.perf_counter()
+                    g[name].replay()
+                    self.host_us[name] = self.host_us.get(name, 0.0) + (time.perf_counter() - t0) * 1e6
+                    self.host_us["_calls_" + name] = self.host_us.get("_calls_" + name, 0) + 1
                 if ev is not None:
                     ev[name][1].record(stream)
 

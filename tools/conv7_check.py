@@ -53,7 +53,7 @@ if "--time" in sys.argv:
         c6.timeit(512, 16, Cin, Cout, (3, 3, 5, 5))
     c6.timeit(512, 16, 64, 64, (3, 3, 3, 3))
     c6.timeit(512, 16, 64, 64, (5, 5, 5, 5))
-if "--check" in sys.argv or "--time" in sys.argv:
+if ("--check" in sys.argv or "--time" in sys.argv) and not any(f in sys.argv for f in ("--check-bwd", "--time-bwd", "--stamps")):
     sys.exit(0 if ok else 1)
 
 
@@ -159,9 +159,57 @@ if "--check-bwd" in sys.argv:
     okb &= check_bwd(11, 16, 64, 64, (3, 3, 5, 5), (2, 5, 8, 11), seed=7)
     okb &= check_bwd(300, 16, 64, 64, (3, 5), (140, 300), seed=8)
     print("BWD ALL OK" if okb else "BWD FAILURES", flush=True)
-    sys.exit(0 if okb else 1)
+    if not okb or not any(f in sys.argv for f in ("--time-bwd", "--stamps")):
+        sys.exit(0 if okb else 1)
 if "--time-bwd" in sys.argv:
     for Cin, Cout in ((32, 32), (64, 64), (96, 32), (64, 32)):
         time_bwd(512, 32, Cin, Cout, (3, 3, 5, 5))
     for Cin, Cout in ((64, 64), (128, 64), (32, 32)):
         time_bwd(512, 16, Cin, Cout, (3, 3, 5, 5))
+
+
+def stamps7(N, R, Cin, Cout, ks):
+    """One conv7 launch with in-kernel stamps of workgroup 0: per wave (tag: cycles since the previous stamp).  tags: 1 start, 2 at a chunk's first
+    stage barrier, 3 past it (tile + weights landed), 4 MFMA stages done, 5 epilogue issued."""
+    import ctypes, torch
+    from hdmoe_hip._lib import call, lib
+    dev = "cuda"
+    x = torch.randn(N, R, R, Cin, device=dev).bfloat16()
+    wd = [torch.randn(Cout, Cin, k, k, device=dev) for k in ks]
+    E = len(ks)
+    seg = torch.tensor([N * i // E for i in range(E + 1)], dtype=torch.int32, device=dev)
+    O, I = Cout, Cin
+    wstride = max(k * k for k in ks) * O * I
+    wf = torch.empty(E * wstride, dtype=torch.bfloat16, device=dev)
+    call("hdmoe_wprep_fwd", wd, None, 1.0, list(ks), list(ks), E, O, I, I, (O + 15) // 16 * 16, wf, wstride, None, 0, 1, 0, 1, 1)
+    y = torch.empty(N, R, R, O, dtype=torch.bfloat16, device=dev)
+    pts = [(k - 1) // 2 for k in ks]
+    args = (x, wf, y, None, 1.0, 0.0, seg, E, wstride, N, R, R, R, R, I, I, I, O, O, 1, 0, list(ks), list(ks), pts, pts, 1)
+    for _ in range(3):
+        call("hdmoe_conv_fwd", *args)
+    buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+    lib().hdmoe_conv6_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
+    call("hdmoe_conv_fwd", *args)
+    torch.cuda.synchronize()
+    lib().hdmoe_conv6_debug_stamps(None)
+    b = buf.cpu().view(8, 64)
+    t0 = min(int(b[w, 0]) & ((1 << 56) - 1) for w in range(8))
+    names = {1: "start", 2: ">bar", 3: "<bar", 4: "mfma'd", 5: "stored", 6: "segs", 7: "zeroed", 8: "consts", 9: "issued"}
+    print(f"stamps N={N} R={R} {Cin}->{Cout} ks={ks}  (s_memtime ticks; tag:delta)")
+    for w in (0, 3, 7):
+        prev, out = t0, []
+        for i in range(64):
+            v = int(b[w, i])
+            if v == 0:
+                break
+            tag, t = (v >> 56) & 0xFF, v & ((1 << 56) - 1)
+            out.append(f"{names.get(tag, tag)}:{t - prev}")
+            prev = t
+        print(f" wave {w}: " + " ".join(out), flush=True)
+
+
+if "--stamps" in sys.argv:
+    stamps7(512, 32, 32, 32, (3, 3, 5, 5))
+    stamps7(512, 32, 32, 32, (3, 3, 5, 5))
+    stamps7(512, 32, 64, 64, (3, 3, 5, 5))
+    stamps7(512, 16, 64, 64, (3, 3, 5, 5))
