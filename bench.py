@@ -490,8 +490,11 @@ def main():
         sec_of = {"unet_s3": "unet_bwd", "unet_s2": "unet_bwd2", "unet_s1": "unet_bwd1", "vit": "vit_bwd", "unet_s0": "unet_bwd0", "rest": "pre_bwd"}
         u0, u1 = stage_ms["unet_bwd"][0], stage_ms["unet_bwd0"][1]
         tot = float(buckets.nbytes())
-        grad_buckets = {t: dict(bytes=4 * b.numel(), final_at_ms=stage_ms[sec_of[t]][1],
-                                frac_of_unet_bwd=round((stage_ms[sec_of[t]][1] - u0) / max(u1 - u0, 1e-9), 3)) for t, b in zip(buckets.tags, buckets.buckets)}
+        end_of = {t: stage_ms[sec_of[t]][1] for t in buckets.tags}
+        if "vr_bwd" in stage_ms:                             # the ViT router's backward is its own section (graph.py SPLIT_VROUTER): same bucket
+            end_of["vit"] = max(end_of["vit"], stage_ms["vr_bwd"][1])
+        grad_buckets = {t: dict(bytes=4 * b.numel(), final_at_ms=end_of[t],
+                                frac_of_unet_bwd=round((end_of[t] - u0) / max(u1 - u0, 1e-9), 3)) for t, b in zip(buckets.tags, buckets.buckets)}
         early = sum(v["bytes"] for v in grad_buckets.values() if v["frac_of_unet_bwd"] <= 0.75)
         grad_buckets["_bytes_final_before_75pct_of_unet_bwd"] = round(early / tot, 3)
     mem_growth = torch.cuda.memory_allocated() - mem0

@@ -14,6 +14,7 @@
 #include "conv7_body.h"
 #include "wgrad6_body.h"
 #include "wgrad7_body.h"
+#include "wgrad8_body.h"
 #include "conv6s_body.h"
 
 namespace {
@@ -45,13 +46,25 @@ __global__ __launch_bounds__(512) void bwd7_kernel(C7Args c, W6Args a3, W6Args a
   const int b = blockIdx.x;
   if (b < G7) { conv7_body<CO, KMASK, TWS == 4>(c, b, G7); return; }
   int r = b - G7;
-  const int bx = r % ibs; r /= ibs;
-  const int by = r % obs;
-  const int z = r / obs;
-  if (TWS == 5 && OT == 0) {                                 // 32 x 32 maps: the streaming weight-gradient program, one 32-channel output chunk per workgroup
-    if (z < a3.chunks) wgrad7_body<3>(a3, bx, by, z);
-    else wgrad7_body<5>(a5, bx, by, z - a3.chunks);
+  if (TWS == 5 && OT == 0) {                                 // 32 x 32 maps: the streaming weight-gradient programs (output chunks of 32)
+    const int icw = a3.icw > 0 ? a3.icw : 1;
+    const int nbx3 = a3.Cin / (32 * icw), nby3 = a3.Cout / (32 * a3.ocw), n3 = nbx3 * nby3 * a3.chunks;
+    if (r < n3) {                                            // 3x3 class: wgrad8, icw x ocw channel chunks per workgroup
+      const int bx = r % nbx3; r /= nbx3;
+      const int by = r % nby3, z = r / nby3, pairs = a3.icw * a3.ocw;
+      if (pairs == 0) wgrad7_body<3>(a3, bx, by, z);         // (HDMOE_WGRAD8=0)
+      else if (pairs == 4) wgrad8_body3<4, 8>(a3, bx, by, z);
+      else if (pairs == 2) wgrad8_body3<2, 8>(a3, bx, by, z);
+      else wgrad8_body3<2, 16>(a3, bx, by, z);
+      return;
+    }
+    r -= n3;
+    const int bx = r % ibs; r /= ibs;
+    wgrad7_body<5>(a5, bx, r % obs, r / obs);
   } else if (OT > 0) {
+    const int bx = r % ibs; r /= ibs;
+    const int by = r % obs;
+    const int z = r / obs;
     if (z < a3.chunks) wgrad6_body<3, TWS, OT == 0 ? 1 : OT, false>(a3, bx, by, z);
     else wgrad6_body<5, TWS, OT == 0 ? 1 : OT, false>(a5, bx, by, z - a3.chunks);
   }
@@ -62,9 +75,10 @@ void launch_bwd7(const C7Plan& cp, const W6DualPlan& wp, hipStream_t stream) {
   static unsigned long long attr = 0;
   if (hdmoe_first_on_device(attr)) { (void)hipFuncSetAttribute((const void*)bwd7_kernel<CO, KMASK, TWS, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   const size_t lds = cp.lds > wp.lds ? cp.lds : wp.lds;
-  const int obs = OT == 0 ? wp.c[0].Cout / 32 : wp.obs;      // OT == 0: wgrad7 (output chunks of 32)
-  const unsigned grid = cp.G + (unsigned)(wp.ibs * obs * (wp.c[0].chunks + wp.c[1].chunks));
-  hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(grid), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, obs);
+  const int obs = OT == 0 ? wp.c[0].Cout / 32 : wp.obs;      // OT == 0: wgrad7 / wgrad8 (output chunks of 32)
+  unsigned nw = (unsigned)(wp.ibs * obs * (wp.c[0].chunks + wp.c[1].chunks));
+  if (OT == 0) nw = (unsigned)((wp.c[0].Cin / (32 * (wp.c[0].icw > 0 ? wp.c[0].icw : 1))) * (wp.c[0].Cout / (32 * wp.c[0].ocw)) * wp.c[0].chunks + wp.ibs * obs * wp.c[1].chunks);
+  hipLaunchKernelGGL((bwd7_kernel<CO, KMASK, TWS, OT>), dim3(cp.G + nw), dim3(512), lds, stream, cp.a, wp.c[0], wp.c[1], (int)cp.G, wp.ibs, obs);
 }
 
 // The same for a router-trunk layer (fp32 tensors on the bf16 pipe: conv6_split program + wgrad6<SPLIT> program).

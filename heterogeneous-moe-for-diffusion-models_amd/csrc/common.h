@@ -26,6 +26,24 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define DEVI __device__ __forceinline__
 
+// ---- transposing LDS reads through inline asm
+// The compiler puts "s_waitcnt vmcnt(0)" in front of every ds_read_b64_tr_b16 it emits itself while an LDS-DMA (buffer_load ... lds) is in
+// flight: it cannot tell that the DMA fills the OTHER buffer, so a kernel that requests the next tile and then reads fragments of this one
+// waits out the whole memory round trip first -- DMA and MFMAs never overlap.  (It does not do this for plain ds_read_b128; found in the ISA of
+// the weight-gradient kernels in round 4, where every k-step of wgrad6 and every unit of wgrad7 paid it.)  The asm forms are invisible to that
+// bookkeeping; in exchange the waits are ours: issue -> lds_tr_wait() -> lds_tr_take() (the take ties the registers to the wait, so no MFMA
+// can be scheduled in front of it).  Addresses are byte offsets into LDS (lds_addr_of).
+typedef __attribute__((ext_vector_type(4))) short hd_s16x4;
+DEVI unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)(p); }
+DEVI void lds_tr2_issue(hd_s16x4& lo, hd_s16x4& hi, unsigned a0, unsigned a1) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1));
+}
+DEVI void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+DEVI bf16x8 lds_tr2_take(hd_s16x4& lo, hd_s16x4& hi) {
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 DEVI float to_f(float v) { return v; }
 DEVI float to_f(bf16 v) { return (float)v; }
 template <typename T> DEVI T from_f(float v);

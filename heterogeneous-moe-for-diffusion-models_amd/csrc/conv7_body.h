@@ -94,30 +94,28 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
   stamp(1);
 
   // ---- unit list: images (pairs of images on 16 x 16 maps) of the groups in descending kernel size, dealt in a snake over the workgroups
-  int cum[HDMOE_MAX_GROUPS + 1], sbeg[HDMOE_MAX_GROUPS], send[HDMOE_MAX_GROUPS];   // (registers: unit_at touches no memory)
+  int cum[HDMOE_MAX_GROUPS + 1];
   cum[0] = 0;
 #pragma unroll
   for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) {
     int cnt = 0;
-    sbeg[i] = 0; send[i] = 0;
-    if (i < a.ngroups) {
-      const int g = a.order[i];
-      sbeg[i] = a.seg ? a.seg[g] : 0; send[i] = a.seg ? a.seg[g + 1] : a.N;
-      cnt = send[i] - sbeg[i];
-    }
+    if (i < a.ngroups) { const int g = a.order[i]; cnt = a.seg ? a.seg[g + 1] - a.seg[g] : a.N; }
     cum[i + 1] = cum[i] + (W16 ? (cnt + 1) >> 1 : cnt);
   }
   const int total = cum[HDMOE_MAX_GROUPS];
   auto unit_at = [&](int q, C7Unit& u) -> bool {
     const int pos = q * G + ((q & 1) ? G - 1 - bid : bid);
     if (pos >= total) return false;
-    int base = 0, g = a.order[0], s0 = sbeg[0], s1 = send[0];
+    int slot = 0;
 #pragma unroll
-    for (int i = 1; i < HDMOE_MAX_GROUPS; ++i)
-      if (i < a.ngroups && pos >= cum[i]) { base = cum[i]; g = a.order[i]; s0 = sbeg[i]; s1 = send[i]; }
+    for (int i = 1; i < HDMOE_MAX_GROUPS; ++i) slot += (i < a.ngroups && pos >= cum[i]) ? 1 : 0;
+    int base = 0, g = 0;
+#pragma unroll
+    for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == slot) { base = cum[i]; g = a.order[i]; }
     int ks = 3;
 #pragma unroll
     for (int i = 0; i < HDMOE_MAX_GROUPS; ++i) if (i == g) ks = a.ks[i];
+    const int s0 = a.seg ? a.seg[g] : 0, s1 = a.seg ? a.seg[g + 1] : a.N;
     u.g = g; u.ks = ks;
     if (W16) { u.n = s0 + 2 * (pos - base); u.n2 = u.n + 1 < s1 ? u.n + 1 : -1; }
     else { u.n = s0 + pos - base; u.n2 = -1; }

@@ -18,6 +18,7 @@
 // Domain: bf16, stride 1, square k in {3, 5}, Cin % 32 == 0, Cout % 32 == 0, W == 16 or W % 32 == 0; everything else: conv.hip.
 #include <stdlib.h>
 #include "common.h"
+#include "conv_args.h"
 #include "hdmoe.h"
 #include "wgrad6_body.h"
 
@@ -115,7 +116,24 @@ __global__ __launch_bounds__(256) void wgrad6_reduce_multi_kernel(W6RBatch b) {
 
 // Pixel partitioning of one kernel-size class: upw tiles per workgroup, `slots` partition slots (an upper bound that holds for any
 // routing: sum over the class's experts of ceil(units_g / upw) <= units_l / upw + ngr).
-void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw, int& slots, bool split, int tpi, const int* kh, int ks) {
+// Workgroups that share one partition slot.  wgrad6 / wgrad7: one per 32-channel input chunk x one per 32 OT output channels.  3x3 classes of
+// bf16 layers on 32 x 32 maps run the wgrad8 program (wgrad8_body.h) in the fused backward launch: 2 x 2 chunks per workgroup where the layer
+// has them, so a slot has a quarter of the workgroups and the class gets four times the slots for the same number of workgroups.
+int w6_wgs_per_slot(int H, int W, int Cin, int Cout, int ks, int dtype, int* icw, int* ocw) {
+  static const bool w8 = !(getenv("HDMOE_WGRAD8") && atoi(getenv("HDMOE_WGRAD8")) == 0);
+  const int OT = Cout % 64 == 0 ? 2 : 1;
+  int ic = 1, oc = 1, n = (Cin / 32) * (Cout / (32 * OT));
+  if (w8 && dtype == HDMOE_BF16 && ks == 3 && H == 32 && W == 32) {
+    ic = Cin % 64 == 0 ? 2 : 1; oc = Cout % 64 == 0 ? 2 : 1;
+    n = (Cin / 32 / ic) * (Cout / 32 / oc);
+  }
+  if (icw) *icw = w8 ? ic : 0;                               // 0: the wgrad7 program (one chunk pair per workgroup) for this class
+  if (ocw) *ocw = oc;
+  return n;
+}
+
+void w6_partition(long units_l, int ngr, int ngroups, int wgs, int& upw, int& slots, bool split, int tpi, const int* kh, int ks) {
+  const int ibs = wgs, obs = 1;
   // Workgroups per kernel-size class.  bf16 expert layers: 128 -- every partition writes (and the reduction re-reads) a whole
   // [tap][O][I] fp32 slab, at 256 a 64->64 layer moved 71 MB of partials for 2 x 17 MB of operands, and in the fused backward launch
   // the 256 conv workgroups fill the chip anyway (same-box A/B 256 -> 128: 16.58 -> 16.15 ms/step).  The fp32 router layers
@@ -126,6 +144,11 @@ void w6_partition(long units_l, int ngr, int ngroups, int ibs, int obs, int& upw
   // Two kernel-size classes in one launch (3x3 and 5x5 experts): the workgroups are shared out by WORK (taps x rows), not evenly -- with 128 + 128
   // the 3x3 class finished in a third of the 5x5 class's time and its CUs idled (round 4; HDMOE_W6_BALANCE=0: the even split)
   static const bool balance = !(getenv("HDMOE_W6_BALANCE") && atoi(getenv("HDMOE_W6_BALANCE")) == 0);
+  // One class alone (the router-trunk layers in bf16-operand mode).  HDMOE_W6_PARTS_SINGLE=256 makes the launch itself 20 % faster on the trunk
+  // shapes (B = 256: 128 -> 128 233 -> 184 us, 64 -> 128 120 -> 92, 32 -> 64 44 -> 38) but the replayed step 0.05 ms SLOWER on the same box: the
+  // router's backward runs beside the U-Net bank's backward, which is the critical path, and more workgroups take CUs from it.  Default: as before.
+  static const long target_one = getenv("HDMOE_W6_PARTS_SINGLE") ? atol(getenv("HDMOE_W6_PARTS_SINGLE")) : target_bf;
+  if (!split && ngr == ngroups) parts = target_one / ((long)ibs * obs);
   if (balance && !split && kh && ngr < ngroups) {
     long wsum = 0;
     for (int g = 0; g < ngroups; ++g) wsum += (long)kh[g] * kh[g];
@@ -172,7 +195,7 @@ int hdmoe_conv_wgrad6_ws_kib(int ngroups, int N, int H, int W, int Cin, int Cout
     int ngr = 0;
     for (int g2 = g; g2 < ngroups; ++g2) if (!done[g2] && kh[g2] == kh[g]) { ++ngr; done[g2] = true; }
     int upw, slots;
-    w6_partition(units_l, ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S, (W / TW) * (int)cdiv(H, TH), kh, kh[g]);
+    w6_partition(units_l, ngr, ngroups, w6_wgs_per_slot(H, W, Cin, Cout, kh[g], dtype, nullptr, nullptr), upw, slots, dtype == HDMOE_F32S, (W / TW) * (int)cdiv(H, TH), kh, kh[g]);
     const long b = (long)slots * kh[g] * kh[g] * Cout * Cin * 4;
     if (b > bytes) bytes = b;
   }
@@ -205,7 +228,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0; a.icw = 1; a.ocw = 1; a.stamps = (unsigned long long*)hdmoe_debug_stamp_buffer();
   const long units_l = (long)N * a.tpi;
   for (int k = 0; k < 2; ++k) {
     const int ks = k == 0 ? 3 : 5;
@@ -214,7 +237,7 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
     for (int g = 0; g < ngroups; ++g) if (kh[g] == ks) { p.c[k].groups[p.c[k].ngr++] = g; p.c[k].pt = pt[g]; p.c[k].pl = pl[g]; }
     p.c[k].ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
-    w6_partition(units_l, p.c[k].ngr, ngroups, p.ibs, p.obs, upw, slots, false, a.tpi, kh, ks);
+    w6_partition(units_l, p.c[k].ngr, ngroups, w6_wgs_per_slot(H, W, Cin, Cout, ks, dtype, &p.c[k].icw, &p.c[k].ocw), upw, slots, false, a.tpi, kh, ks);
     p.c[k].upw = upw; p.c[k].chunks = p.c[k].ngr ? slots : 0;
   }
   // workspace regions in the order the classes appear in the group list (what hdmoe_conv_wgrad6_reduce_batch assumes)
@@ -244,12 +267,12 @@ int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int*
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0; a.icw = 1; a.ocw = 1; a.stamps = (unsigned long long*)hdmoe_debug_stamp_buffer();
   a.ngr = 0;
   for (int g = 0; g < ngroups; ++g) a.groups[a.ngr++] = g;
   a.pt = 1; a.pl = 1; a.ws_item = 9l * Cout * Cin;
   int upw, slots;
-  w6_partition((long)N * a.tpi, a.ngr, ngroups, p.ibs, p.obs, upw, slots, true, a.tpi, kh, 3);
+  w6_partition((long)N * a.tpi, a.ngr, ngroups, p.ibs * p.obs, upw, slots, true, a.tpi, kh, 3);
   a.upw = upw; a.chunks = slots;
   p.c[1] = a; p.c[1].chunks = 0;
   const int HP16 = ((TW + 2) * (TH + 2) + 15) / 16;
@@ -284,7 +307,7 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
   a.x = x; a.dy = dy; a.ws = (float*)ws; a.seg = seg; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.tiles_x = W / TW; a.tpi = a.tiles_x * (int)cdiv(H, TH);
   a.xbytes = (int)xbytes; a.dybytes = (int)dybytes;
-  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.hi_only = 0; a.icw = 1; a.ocw = 1; a.stamps = (unsigned long long*)hdmoe_debug_stamp_buffer();
   const long units_l = (long)N * a.tpi;
   bool done[HDMOE_MAX_GROUPS] = {false};
   int cls = 0;
@@ -316,7 +339,7 @@ int hdmoe_conv_wgrad6(const void* x, const void* dy, float* const* G, const int*
     ++cls;
     a.ws_item = (long)ks * ks * Cout * Cin;
     int upw, slots;
-    w6_partition(units_l, a.ngr, ngroups, ibs, obs, upw, slots, dtype == HDMOE_F32S, a.tpi, kh, ks);
+    w6_partition(units_l, a.ngr, ngroups, ibs * obs, upw, slots, dtype == HDMOE_F32S, a.tpi, kh, ks);
     a.upw = upw; a.chunks = slots;                          // (chunks = partition slots of this class)
     const W6Args& b = a;                                    // (kernel-size classes reuse the workspace: each class's reduce runs before the next class)
 #define W6_LAUNCH(K, T, O) launch_w6<K, T, O, false>(b, ibs, obs, stream)
@@ -368,7 +391,7 @@ int hdmoe_conv_wgrad6_reduce_batch(float* const* G, const int* const* seg, float
         if (!done[g2] && kh[g2] == kh[g]) { it.groups[it.ngr] = g2; it.G[it.ngr] = G[8 * i + g2]; ++it.ngr; done[g2] = true; }
       for (int k = it.ngr; k < HDMOE_MAX_GROUPS; ++k) { it.groups[k] = 0; it.G[k] = nullptr; }
       int upw, slots;
-      w6_partition(units_l, it.ngr, ngroups, Cin / 32, Cout / (32 * OT), upw, slots, dtype == HDMOE_F32S, tpi, kh, kh[g]);
+      w6_partition(units_l, it.ngr, ngroups, w6_wgs_per_slot(H, W, Cin, Cout, kh[g], dtype, nullptr, nullptr), upw, slots, dtype == HDMOE_F32S, tpi, kh, kh[g]);
       it.ws = (const float*)((const char*)ws[i] + (long)cls * need1);
       it.seg = seg[i]; it.N = N; it.tpi = tpi; it.upw = upw;
       it.ws_item = (long)kh[g] * kh[g] * Cout * Cin;

@@ -16,6 +16,8 @@ struct W6Args {
   // the tile is staged -- the normalised activation is never materialised; padding pixels stay zero).  Null = plain x.
   const float* in_scale; const float* in_shift; int in_relu;
   int hi_only;                        // SPLIT only: 1 = drop the two hi x lo correction products (bf16 operands, fp32 accumulation)
+  int icw, ocw;                       // wgrad8 (3x3, 32 x 32 maps): 32-channel chunks per workgroup on the input / output side (1 or 2)
+  unsigned long long* stamps;         // development: s_memtime stamps (wgrad7 program, first workgroup of each class), or null
 };
 struct W6DualPlan { W6Args c[2]; int ibs, obs, TWS, OT; size_t lds; };
 // Launch geometry of the deferred dual-class bf16 weight gradient of one layer (wgrad6.hip).  0 = planned, 1 = not applicable.
@@ -26,7 +28,13 @@ int wgrad6_plan_dual(const void* x, const void* dy, float* const* G, const int* 
 int wgrad6_plan_split(const void* x, const void* dy, float* const* G, const int* seg, int ngroups, int N, int H, int W, int Cin, int Cout,
                       const int* kh, const int* kw, const int* pt, const int* pl, void* ws, long ws_bytes, W6DualPlan& p);
 
+#include <type_traits>
+#include <utility>
+
 namespace {
+
+template <typename F, int... I> DEVI void w6_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> DEVI void w6_static_for(F&& f) { w6_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -48,6 +56,7 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
   constexpr int XBUF = HP16 * 1024, DYBUF = DYP * 1024, BUF = XBUF + DYBUF;   // SPLIT: buffer 0 = hi planes, buffer 1 = lo planes
   constexpr int NXP = (HP16 + 7) / 8, NDP = DYP / 8;        // DMA pieces per wave
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const unsigned lds0 = lds_addr_of(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
@@ -57,8 +66,8 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
   int gi = 0, chunk = zslot, row0 = 0, units = 0;
   for (; gi < a.ngr; ++gi) {
     const int g = a.groups[gi];
-    row0 = a.seg ? a.seg[g] : 0;
-    units = ((a.seg ? a.seg[g + 1] : a.N) - row0) * a.tpi;
+    row0 = a.seg ? __builtin_amdgcn_readfirstlane(a.seg[g]) : 0;               // (scalar: see wgrad8_body.h w8_slot)
+    units = ((a.seg ? __builtin_amdgcn_readfirstlane(a.seg[g + 1]) : a.N) - row0) * a.tpi;
     const int nch = (units + a.upw - 1) / a.upw;
     if (chunk < nch) break;
     chunk -= nch;
@@ -273,30 +282,41 @@ DEVI void wgrad6_body(const W6Args& a, const int bx, const int by, const int zsl
     if (more) tile_origin(u + 1, nn, nty0, ntx0);
     const int xb = par * BUF, dyb = par * BUF + XBUF;
     // pixels of this tile that lie inside the image take part (rows past the image bottom were DMA'd as zeros: no masking needed)
+    // Fragments through the asm transposing reads (common.h), requested one k-step ahead: the compiler's own reads wait for the DMA piece
+    // issued in the previous k-step (a memory round trip per k-step) and sit right in front of their MFMAs.
+    hd_s16x4 plo[2][OT + NFULL + 1], phi[2][OT + NFULL + 1];
+    auto request = [&](auto ks_c, int set) {
+      constexpr int ks = decltype(ks_c)::value;
+      constexpr int krow = (16 * ks) >> TWS, kcol = (16 * ks) & (TW - 1);
+      constexpr int kx_off = (krow * HWp + kcol) * 64, kdy_off = 16 * ks * DYROW;   // halo offset of the k-step's first pixel: tile pixel 16 ks -> (row, column)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      // halo offset of the k-step's first pixel (compile time): tile pixel 16 ks -> (row, column)
-      const int krow = (16 * ks) >> TWS, kcol = (16 * ks) & (TW - 1);
-      const int kx_off = (krow * HWp + kcol) * 64;            // folds into the instruction offset
-      const int kdy_off = 16 * ks * DYROW;
+      for (int t = 0; t < OT; ++t) { const unsigned ad = lds0 + dyb + dylane[t] + kdy_off; lds_tr2_issue(plo[set][t], phi[set][t], ad, ad + 4 * DYROW); }
+#pragma unroll
+      for (int s2 = 0; s2 <= NFULL; ++s2) { const unsigned ad = lds0 + xb + xlane + tapoff[s2] + kx_off; lds_tr2_issue(plo[set][OT + s2], phi[set][OT + s2], ad, ad + 4 * 64); }
+    };
+    request(std::integral_constant<int, 0>{}, 0);
+    w6_static_for<16>([&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+      lds_tr_wait();
       bf16x8 fdy[OT], fdye, fx[NFULL], fxe;
 #pragma unroll
-      for (int t = 0; t < OT; ++t) fdy[t] = tr2(dyb + dylane[t] + kdy_off, 4 * DYROW);
+      for (int t = 0; t < OT; ++t) fdy[t] = lds_tr2_take(plo[ks & 1][t], phi[ks & 1][t]);
 #pragma unroll
-      for (int s = 0; s < NFULL; ++s) fx[s] = tr2(xb + xlane + tapoff[s] + kx_off, 4 * 64);
+      for (int s2 = 0; s2 < NFULL; ++s2) fx[s2] = lds_tr2_take(plo[ks & 1][OT + s2], phi[ks & 1][OT + s2]);
+      fxe = lds_tr2_take(plo[ks & 1][OT + NFULL], phi[ks & 1][OT + NFULL]);
       fdye = (OT == 2 && eob) ? fdy[OT - 1] : fdy[0];           // wave-uniform select: the left-over tile's channel half
-      fxe = tr2(xb + xlane + tapoff[NFULL] + kx_off, 4 * 64);
+      if (ks + 1 < 16) request(std::integral_constant<int, (ks + 1 < 16 ? ks + 1 : 0)>{}, (ks + 1) & 1);
       // next tile's DMA pieces, one per k-step
       if (more) {
         if (ks < NXP) issue_x(nn, nty0, ntx0, ks, par ^ 1);
         else if (ks - NXP < NDP) issue_dy(nn, nty0, ntx0, ks - NXP, par ^ 1);
       }
 #pragma unroll
-      for (int s = 0; s < NFULL; ++s)
+      for (int s2 = 0; s2 < NFULL; ++s2)
 #pragma unroll
-        for (int t = 0; t < OT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy[t], fx[s], acc[s][t], 0, 0, 0);
+        for (int t = 0; t < OT; ++t) acc[s2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy[t], fx[s2], acc[s2][t], 0, 0, 0);
       acce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdye, fxe, acce, 0, 0, 0);
-    }
+    });
     par ^= 1;
   }
   }

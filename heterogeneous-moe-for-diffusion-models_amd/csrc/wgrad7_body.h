@@ -31,13 +31,21 @@ DEVI void wgrad7_body(const W6Args& a, const int bx, const int by, const int zsl
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = bx * 32, o0 = by * 32;
+  int nstamp = 0;
+  auto stamp = [&](int tag) {
+    if (a.stamps && bx == 0 && by == 0 && zslot == 0 && lane == 0 && nstamp < 63) {
+      a.stamps[(KS == 3 ? 512 : 1024) + wave * 64 + nstamp] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull);
+      ++nstamp;
+    }
+  };
+  stamp(1);
   // partition slot -> (expert of this class, image range): experts take ceil(units / upw) consecutive slots each (upw: 256-pixel tiles, a
   // multiple of the 4 tiles of an image -- w6_partition)
   int gi = 0, chunk = zslot, row0 = 0, units = 0;
   for (; gi < a.ngr; ++gi) {
     const int g = a.groups[gi];
-    row0 = a.seg ? a.seg[g] : 0;
-    units = ((a.seg ? a.seg[g + 1] : a.N) - row0) * a.tpi;
+    row0 = a.seg ? __builtin_amdgcn_readfirstlane(a.seg[g]) : 0;               // (scalar: see wgrad8_body.h w8_slot)
+    units = ((a.seg ? __builtin_amdgcn_readfirstlane(a.seg[g + 1]) : a.N) - row0) * a.tpi;
     const int nch = (units + a.upw - 1) / a.upw;
     if (chunk < nch) break;
     chunk -= nch;
@@ -89,20 +97,19 @@ DEVI void wgrad7_body(const W6Args& a, const int bx, const int by, const int zsl
     const int tt = tvalid[j] ? t : 0;
     xoff[j] = (tt / KS) * XROWB + (tt % KS + Q) * 64;
   }
-  typedef __attribute__((address_space(3))) s16x4* lds_p;
-  auto tr2 = [&](int addr) -> bf16x8 {                         // pixels 0..3 at addr, 4..7 at addr + 256
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + addr));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + addr + 256));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-  };
+  const unsigned lds0 = lds_addr_of(lds);
 
   f32x16 acc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) acc[j] = (f32x16)(0.f);
 
+  stamp(2);
   if (U > 0) issue_unit(0, 0);
+  stamp(3);
   for (int u = 0; u < U; ++u) {
+    stamp(4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // unit u has landed; the other stage is free again
+    stamp(5);
     const int sb = (u & 1) * STAGE;
     if (u + 1 < U) issue_unit(u + 1, STAGE - sb);
     const int dyb = sb + XB + lbase + pp * RPW * 2048;
@@ -112,23 +119,32 @@ DEVI void wgrad7_body(const W6Args& a, const int bx, const int by, const int zsl
 #pragma unroll
     for (int b = 0; b < RPW * 2; ++b) {                         // 16-pixel blocks of this wave's rows: (row b >> 1, half b & 1)
       const int rr = b >> 1, hh = b & 1;
-      const bf16x8 fdy = tr2(dyb + rr * 2048 + hh * 1024);
+      // all fragments of the block requested at once through the asm reads (common.h: the compiler's own transposing reads would wait for
+      // the next unit's DMA first), one wait, then the MFMAs
+      hd_s16x4 dlo, dhi, xlo[TPW], xhi[TPW];
+      lds_tr2_issue(dlo, dhi, lds0 + dyb + rr * 2048 + hh * 1024, lds0 + dyb + rr * 2048 + hh * 1024 + 256);
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        if (NTAPS % NG == 0 || j + 1 < TPW || tvalid[j]) {     // (only a group's last tap can be missing)
-          const bf16x8 fx = tr2(xb[j] + rr * XROWB + hh * 1024);
+        const unsigned ad = lds0 + xb[j] + rr * XROWB + hh * 1024;
+        lds_tr2_issue(xlo[j], xhi[j], ad, ad + 256);
+      }
+      lds_tr_wait();
+      const bf16x8 fdy = lds_tr2_take(dlo, dhi);
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const bf16x8 fx = lds_tr2_take(xlo[j], xhi[j]);
+        if (NTAPS % NG == 0 || j + 1 < TPW || tvalid[j])       // (only a group's last tap can be missing)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy, fx, acc[j], 0, 0, 0);
-        }
       }
     }
   }
-
+  stamp(6);
   // ---- the NP pixel parts of every tap meet in LDS (fixed order), then leave as 128-byte-run stores into the slot's partial slab
   float* Pw = a.ws + (long)zslot * a.ws_item;
   float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tiles (first round) / the previous round's sums are consumed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tiles (first round) / the previous round's sums are consumed (no vmcnt: the DMA was drained at the last unit's barrier, the stores stay in flight)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) red[wave * 1024 + reg * 64 + lane] = acc[j][reg];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -146,6 +162,7 @@ DEVI void wgrad7_body(const W6Args& a, const int bx, const int by, const int zsl
       }
     }
   }
+  stamp(7);
 #endif
 }
 

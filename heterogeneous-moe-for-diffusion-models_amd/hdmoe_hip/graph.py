@@ -76,7 +76,16 @@ class Stager:
     ``graph.current()``: ``cut(stage, **tensors_by_producer_stage)`` at a boundary, ``backward(loss)`` instead of loss.backward()."""
 
     KIND = {"pre": "main", "ur": "r", "unet": "u", "vit": "v", "post": "main", "ucomb_bwd": "u", "ur_bwd": "r", "unet_bwd": "u", "vit_bwd": "v",
-            "pre_bwd": "main", "unet_bwd2": "u", "unet_bwd1": "u", "unet_bwd0": "u"}
+            "pre_bwd": "main", "unet_bwd2": "u", "unet_bwd1": "u", "unet_bwd0": "u", "vcomb_bwd": "v", "vr_bwd": "r"}
+    # SPLIT_VROUTER (round 4): with the U-Net bank's backward down to ~6 ms the ViT section became the LAST one to finish (stage_ms: vit_bwd
+    # 6.2 -> 12.8 ms, unet_bwd0 ends at 12.4): its stream runs the ViT bank's backward (~170 small launches) and then the ViT router's trunk
+    # backward (the heavy part) one after the other.  The router's backward needs only the gradient of the routing weights, which the
+    # combine backward -- the section's first kernel -- produces: same cut as for the U-Net router (`vcomb_bwd` on the ViT stream, then
+    # `vr_bwd` beside `vit_bwd`).  The forward stays one graph.  HDMOE_VR_STREAM: the stream of `vr_bwd`.  Same box, ms/step: no split 13.39;
+    # "r" (behind the U-Net router's backward; default) 13.13; "main" (idle between `post` and `pre_bwd`, but prioritised like the U-Net
+    # stream: it takes CUs from the critical path) 13.32; "r2" (a fifth stream of our own) 17.9 -- see the note on hardware queues below.
+    SPLIT_VROUTER = __import__("os").environ.get("HDMOE_SPLIT_VROUTER", "1") != "0"
+    KIND["vr_bwd"] = __import__("os").environ.get("HDMOE_VR_STREAM", "r")
     # SPLIT_UNET_BWD (round 4): the U-Net bank's backward as up to FOUR sections on its stream -- decoder at full resolution (+ output conv),
     # decoder below, encoder below, encoder at full resolution (+ embeddings) -- cut with detached leaves inside the forward graph
     # (models/model_components.py unet_expert_bank_forward).  Each section finishes its own weight gradients (bank.finish_stage), so its
@@ -173,7 +182,12 @@ class Stager:
                 for k in (2, 1, 0):
                     if self.cuts.get(f"unet_c{k}"):
                         self._section(f"unet_bwd{k}", f"unet_c{k}")
-            self._section("vit_bwd", "vit")
+            if self.cuts.get("vcomb"):                            # SPLIT_VROUTER: combine backward, then the bank and the router side by side
+                self._section("vcomb_bwd", "vcomb")
+                self._section("vit_bwd", "vit")
+                self._section("vr_bwd", "vr")
+            else:
+                self._section("vit_bwd", "vit")
             self._section("pre_bwd", "pre")
         finally:
             bank.DEFER_FINISH = False
@@ -227,8 +241,10 @@ class StagedStep:
         pmode = __import__("os").environ.get("HDMOE_STREAM_PRIO", "auto")
         use_prio = pmode == "1" or (pmode == "auto" and not (dist.is_available() and dist.is_initialized()))
         prio = {"main": -1, "u": -1, "v": 0, "r": 0} if use_prio else {"main": 0, "u": 0, "v": 0, "r": 0}
-        self.streams = {k: torch.cuda.Stream(device=self.device, priority=prio[k]) for k in ("main", "u", "v", "r")}
-        self.pools = {k: torch.cuda.graph_pool_handle() for k in ("main", "u", "v", "r")}
+        names = ("main", "u", "v", "r") + (("r2",) if Stager.KIND["vr_bwd"] == "r2" else ())
+        prio["r2"] = 0
+        self.streams = {k: torch.cuda.Stream(device=self.device, priority=prio[k]) for k in names}
+        self.pools = {k: torch.cuda.graph_pool_handle() for k in names}
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams.values():
             s.wait_stream(cur)
@@ -238,7 +254,8 @@ class StagedStep:
             cur.wait_stream(s)
         torch.cuda.synchronize(self.device)
         st = self._run(step_fn, capture=True)
-        core = [n for n in st.order if n not in ("unet_bwd2", "unet_bwd1", "unet_bwd0")]
+        core = [n for n in st.order if n not in ("unet_bwd2", "unet_bwd1", "unet_bwd0", "vcomb_bwd", "vr_bwd")]
+        self.split_vr = "vr_bwd" in st.order                      # the ViT router's backward as its own section (Stager.SPLIT_VROUTER)
         if core not in (self.ORDER, self.ORDER_R):
             raise RuntimeError(f"staged step: unexpected stage sequence {st.order}")
         self.split_router = core == self.ORDER_R
@@ -312,10 +329,18 @@ class StagedStep:
             run("post", main)
             u.wait_stream(main); v.wait_stream(main)
             run("ucomb_bwd", u)
+            vr_s = S[self._keep.KIND["vr_bwd"]] if self.split_vr else None
+            if self.split_vr:
+                run("vcomb_bwd", v)
             r.wait_stream(u)
             run("unet_bwd", u)
             run("ur_bwd", r)
+            if self.split_vr:
+                vr_s.wait_stream(v)                               # (behind the combine backward; on "r" also behind ur_bwd: stream order)
+                run("vr_bwd", vr_s)
             run("vit_bwd", v)
+            if self.split_vr:
+                v.wait_stream(vr_s)                               # the "vit" gradient bucket holds the ViT router's parameters too
             if self.unet_sub:
                 # the bank's sections one after the other on its stream; behind each the hook that hands its gradient bucket on
                 # (buckets are ordered by completion: decoder sections first, then the ViT branch, then what ends with the backward)

@@ -29,8 +29,9 @@ VIT_BANK = __import__("os").environ.get("HDMOE_VIT_BANK", "1") != "0"
 
 
 def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_emb: Tensor, text2d: Optional[Tensor],
-                   kcap: Optional[int] = None, stager=None) -> Tensor:
-    """x channel-last (B,H,W,C) -> (B,H,W,C).  ``stager``: cut the autograd graph between the bank and the combine (staged step)."""
+                   kcap: Optional[int] = None, stager=None, cut_name: str = "unet") -> Tensor:
+    """x channel-last (B,H,W,C) -> (B,H,W,C).  ``stager``: cut the autograd graph between the bank and the combine (staged step); the bank's
+    output rows then belong to the backward section of producer ``cut_name``."""
     mods = list(experts)
     E = len(mods)
 
@@ -58,9 +59,9 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         xs = ops.gather_rows(x, plan)
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
-        ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg, stager=stager)
+        ys = m.unet_expert_bank_forward(mods, xs, ts, tx, plan.seg, stager=stager if cut_name == "unet" else None)
         if stager is not None:
-            (ys,) = stager.cut_local(unet=(ys,))
+            (ys,) = stager.cut_local(**{cut_name: (ys,)})
         return ops.combine_rows(ys, out_router, plan)
     if VIT_BANK and m.vit_bank_compatible(mods, x.shape[1], x.shape[2]):
         plan = ops.DispatchPlan(out_router, kcap if kcap is not None else E)
@@ -69,6 +70,8 @@ def _dispatch_nhwc(x: Tensor, experts: nn.ModuleList, out_router: Tensor, time_e
         ts = ops.gather_rows(time_emb, plan)
         tx = None if text2d is None else ops.gather_rows(text2d, plan)
         ys = m.vit_expert_bank_forward(mods, xs, ts, tx, plan.seg)
+        if stager is not None:
+            (ys,) = stager.cut_local(**{cut_name: (ys,)})
         return ops.combine_rows(ys, out_router, plan)
     note_usage(None)
     return _combine_weighted(_run_experts(x, mods, time_emb, text2d), out_router)
@@ -231,11 +234,22 @@ class _HDMOEMBase(nn.Module):
                 (te_r, te_b), (in_r, in_b) = ops.fanout(te_u, 2), ops.fanout(in_u, 2)
                 w_unet, p_unet, raw_unet, _ = self.Unet_router._fwd(in_r, te_r, Unet_router_mask, zeta)
                 out_u = _dispatch_nhwc(ops.cast(in_b, cdt), self.Unet_experts, w_unet, te_b, text2d, kcap=self.top_k)
+            split_vr = st.SPLIT_ROUTER and st.SPLIT_VROUTER
             te_v, in_v = st.cut("vit", pre=(te, in_vit))
-            (te_r, te_b), (in_r, in_b) = ops.fanout(te_v, 2), ops.fanout(in_v, 2)
-            w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_r, te_r, Vit_router_mask, zeta)
-            out_v = _dispatch_nhwc(ops.cast(in_b, cdt), self.VIT_experts, w_vit, te_b, text2d, kcap=self.top_k)
-            if st.SPLIT_ROUTER:
+            if split_vr:
+                # one forward graph, three backward sections (hdmoe_hip/graph.py SPLIT_VROUTER): the router sees its own leaves of the stem
+                # tensors, the bank a detached copy of the routing weights; the combine is the boundary between them
+                w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_v, te_v, Vit_router_mask, zeta)
+                te_b, in_b, w_b = st.cut_local(pre=(te, in_vit), vr=(w_vit,))
+                out_v = _dispatch_nhwc(ops.cast(in_b, cdt), self.VIT_experts, w_b, te_b, text2d, kcap=self.top_k, stager=st, cut_name="vit")
+            else:
+                (te_r, te_b), (in_r, in_b) = ops.fanout(te_v, 2), ops.fanout(in_v, 2)
+                w_vit, p_vit, raw_vit, _ = self.vit_router._fwd(in_r, te_r, Vit_router_mask, zeta)
+                out_v = _dispatch_nhwc(ops.cast(in_b, cdt), self.VIT_experts, w_vit, te_b, text2d, kcap=self.top_k)
+            if split_vr:
+                out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
+                    "post", ucomb=(out_u,), ur=(p_unet, raw_unet), vcomb=(out_v,), vr=(p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
+            elif st.SPLIT_ROUTER:
                 out_u, p_unet, raw_unet, out_v, p_vit, raw_vit, s_vit, s_unet, scaling = st.cut(
                     "post", ucomb=(out_u,), ur=(p_unet, raw_unet), vit=(out_v, p_vit, raw_vit), pre=(s_vit, s_unet, scaling))
             else:

@@ -1660,7 +1660,8 @@ def test_staged_step_matches_plain_backward(dtype, tol):
         finally:
             hgraph.Stager.SPLIT_ROUTER = split_saved
         # (config1 / ten graphs: the U-Net bank's backward additionally runs as four sections -- Stager.SPLIT_UNET_BWD)
-        want = hgraph.StagedStep.ORDER_R + ["unet_bwd2", "unet_bwd1", "unet_bwd0"] if mod is model_config1 else hgraph.StagedStep.ORDER
+        # (... and the ViT router's backward is its own section behind the combine backward -- Stager.SPLIT_VROUTER)
+        want = hgraph.StagedStep.ORDER_R + ["unet_bwd2", "unet_bwd1", "unet_bwd0", "vcomb_bwd", "vr_bwd"] if mod is model_config1 else hgraph.StagedStep.ORDER
         assert sorted(staged.graphs) == sorted(want) and hgraph.current() is None
         for _ in range(3):
             l_g = staged()
@@ -1682,6 +1683,8 @@ def test_staged_step_matches_plain_backward(dtype, tol):
         t = staged.stage_times()
         assert t["unet"][0] >= t["pre"][1] - 1e-3 and t["post"][0] >= max(t["unet"][1], t["vit"][1]) - 1e-3
         assert t["pre_bwd"][0] >= max(t["unet_bwd"][1], t["vit_bwd"][1]) - 1e-3
+        if "vr_bwd" in t:                                           # both ViT sections wait for the combine backward; the stem backward waits for both
+            assert min(t["vit_bwd"][0], t["vr_bwd"][0]) >= t["vcomb_bwd"][1] - 1e-3 and t["pre_bwd"][0] >= t["vr_bwd"][1] - 1e-3
         if "unet_bwd0" in t:                                        # the bank's sections follow one another on its stream
             assert t["unet_bwd2"][0] >= t["unet_bwd"][1] - 1e-3 and t["unet_bwd0"][0] >= t["unet_bwd1"][1] - 1e-3 and t["pre_bwd"][0] >= t["unet_bwd0"][1] - 1e-3
         # Regression (found with a one-rank RCCL group: the barrier's tensor allocation between two replays): a replay must not depend

@@ -156,6 +156,11 @@ if "--check-bwd" in sys.argv:
     okb &= check_bwd(7, 32, 64, 32, (3, 5, 3), (2, 5, 7), seed=4)
     okb &= check_bwd(6, 32, 32, 32, (5, 3), (6, 6), seed=5)               # empty 3x3 class member
     okb &= check_bwd(300, 32, 32, 32, (3, 3, 5, 5), (70, 150, 210, 300), seed=6)
+    okb &= check_bwd(20, 32, 128, 128, (3,), (20,), seed=9)               # 2 x 2 chunk pairs per workgroup (router-trunk shape)
+    okb &= check_bwd(12, 32, 64, 128, (3, 3), (5, 12), seed=10)
+    okb &= check_bwd(9, 32, 32, 64, (3, 5), (4, 9), seed=11)              # 1 x 2 chunks
+    okb &= check_bwd(13, 32, 128, 32, (5, 3), (6, 13), seed=12)           # 2 x 1 chunks
+    okb &= check_bwd(210, 32, 64, 64, (3, 3, 5, 5), (50, 110, 160, 210), seed=13)
     okb &= check_bwd(11, 16, 64, 64, (3, 3, 5, 5), (2, 5, 8, 11), seed=7)
     okb &= check_bwd(300, 16, 64, 64, (3, 5), (140, 300), seed=8)
     print("BWD ALL OK" if okb else "BWD FAILURES", flush=True)
@@ -166,6 +171,8 @@ if "--time-bwd" in sys.argv:
         time_bwd(512, 32, Cin, Cout, (3, 3, 5, 5))
     for Cin, Cout in ((64, 64), (128, 64), (32, 32)):
         time_bwd(512, 16, Cin, Cout, (3, 3, 5, 5))
+    for Cin, Cout in ((128, 128), (64, 128), (32, 64)):                    # router-trunk layers (one 3x3 class)
+        time_bwd(256, 32, Cin, Cout, (3,))
 
 
 def stamps7(N, R, Cin, Cout, ks):
@@ -213,3 +220,39 @@ if "--stamps" in sys.argv:
     stamps7(512, 32, 32, 32, (3, 3, 5, 5))
     stamps7(512, 32, 64, 64, (3, 3, 5, 5))
     stamps7(512, 16, 64, 64, (3, 3, 5, 5))
+
+
+def stamps_bwd(N, R, Cin, Cout, ks):
+    """One fused backward launch with in-kernel stamps: dgrad workgroup 0 and the first weight-gradient workgroup of each class.
+    wgrad7 tags: 1 start, 2 slot decoded, 3 first unit issued, 4 / 5 before / after a unit's barrier, 6 MFMAs done, 7 reduced and stored."""
+    import ctypes, torch
+    from hdmoe_hip._lib import call, lib
+    E = len(ks)
+    split = [N * (i + 1) // E for i in range(E)]
+    x, dy, ws, seg, Gs, dx, segd, wsb, args, dims = _bwd_setup(N, R, Cin, Cout, ks, split, 1)
+    for _ in range(3):
+        call("hdmoe_conv_bwd6", *args)
+    buf = torch.zeros(3 * 512, dtype=torch.int64, device="cuda")
+    lib().hdmoe_conv6_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
+    call("hdmoe_conv_bwd6", *args)
+    torch.cuda.synchronize()
+    lib().hdmoe_conv6_debug_stamps(None)
+    b = buf.cpu().view(3, 8, 64)
+    t0 = min(int(b[0, w, 0]) & ((1 << 56) - 1) for w in range(8))
+    print(f"bwd stamps N={N} R={R} {Cin}->{Cout} ks={ks}  (s_memtime ticks since the dgrad workgroup's start; tag:delta)")
+    for sect, nm in ((0, "dgrad"), (1, "wgrad 3x3"), (2, "wgrad 5x5")):
+        for w in (0, 7):
+            prev, out = t0, []
+            for i in range(64):
+                v = int(b[sect, w, i])
+                if v == 0:
+                    break
+                tag, t = (v >> 56) & 0xFF, v & ((1 << 56) - 1)
+                out.append(f"{tag}:{t - prev}")
+                prev = t
+            print(f" {nm} wave {w}: " + " ".join(out), flush=True)
+
+
+if "--stamps-bwd" in sys.argv:
+    stamps_bwd(512, 32, 32, 32, (3, 3, 5, 5))
+    stamps_bwd(512, 32, 64, 64, (3, 3, 5, 5))
