@@ -91,6 +91,8 @@ def pmc_traffic(kernel_name):
         args = "".join(("Lb1E" if a == "true" else "Lb0E" if a == "false" else f"Li{a}E") for a in m.group(2).split(", ") if a.strip("-").isdigit() or a in ("true", "false"))
         keys = [f"{m.group(1)}IDF16b{args}"]
     keys = [k.split(" (")[0].replace("<split>", "") for k in keys]          # "wgrad6_kernel (+ reduce)" -> "wgrad6_kernel"
+    if "bwd6_kernel" in keys:                                # the fused dgrad + weight-gradient launch of the expert layers: bwd6_kernel or, on
+        keys.append("bwd7_kernel")                           # 32 x 32 / 16 x 16 maps, bwd7_kernel (the streaming programs) -- one family
     tot = n = 0.0
     for k, v in tbl.items():                                # launch-weighted mean over the instantiations of the kernel
         if any(key in k for key in keys):
@@ -188,6 +190,20 @@ def roofline_leg(step_fn, n_steps):
     # (measured on these kernels with SQ_ACTIVE_INST_VALU at a 2.08 GHz clock: ~16 VALU-active cycles per v_exp_f32 wave instruction --
     #  against THAT rate the forward is at ~75 %, the backward kernels at 80-90 % of their instruction-issue floors)
     exp_peak = 1024 * 64 / 8 * 2.4e9
+    # ... and the rate itself, measured: 8 independent chains of dependent v_exp_f32 per thread, 16 waves per SIMD, nothing else in the loop
+    exp_meas = None
+    try:
+        from hdmoe_hip._lib import call as _call
+        blocks, iters = 256 * 16, 4096
+        buf = torch.empty(blocks * 256, dtype=torch.float32, device="cuda")
+        _call("hdmoe_exp_rate", buf, blocks, 64)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); _call("hdmoe_exp_rate", buf, blocks, iters); e1.record()
+        torch.cuda.synchronize()
+        exp_meas = blocks * 256 * 8.0 * iters / (e0.elapsed_time(e1) * 1e-3)
+    except Exception as ex:                                  # (an old library without the entry point)
+        print(f"exp rate microbenchmark skipped: {ex}", file=sys.stderr)
     rep = []
     for key, t in sorted(attn.items(), key=lambda kv: -sum(kv[1]["ms"])):
         i = t["info"]
@@ -199,6 +215,8 @@ def roofline_leg(step_fn, n_steps):
         hbm = i["B"] * E * i["esz"] * ((2 * i["Sq"] + 2 * i["Skv"]) if i["dir"] == "fwd" else (5 * i["Sq"] + 4 * i["Skv"]))
         rep.append(dict(shape=key, median_ms=round(ms, 4), launches_per_step=len(t["ms"]) / n_steps, exps_per_s=round(exps / (ms * 1e-3), 1),
                         exp_issue_bound_per_s=exp_peak, frac_of_exp_bound=round(exps / (ms * 1e-3) / exp_peak, 4),
+                        exp_rate_measured_per_s=None if exp_meas is None else round(exp_meas, 1),
+                        frac_of_measured_exp_rate=None if exp_meas is None else round(exps / (ms * 1e-3) / exp_meas, 4),
                         hbm_floor_us=round(hbm / 6.3e12 * 1e6, 2), frac_of_hbm_floor=round(hbm / 6.3e12 / (ms * 1e-3), 4)))
     roofline_leg.attention = rep[:4] or None
     if not agg:

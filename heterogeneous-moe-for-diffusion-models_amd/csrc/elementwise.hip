@@ -975,6 +975,22 @@ __global__ void sum_n_kernel(T* out, SumSrcs s, int n, long nv, long nelem) {
 
 #define L1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, __VA_ARGS__)
 
+// Measurement aid (bench.py "attention", tools/exp_rate.py): issue rate of v_exp_f32, the instruction that bounds the attention kernels.
+// Every thread runs 8 independent chains a = exp2(-a) (the negation is a source modifier: one v_exp_f32 per link), `iters` links each.
+__global__ __launch_bounds__(256) void exp_rate_kernel(float* out, int iters) {
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = 0.25f + 0.001f * (float)((threadIdx.x + k) & 63);
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = __builtin_amdgcn_exp2f(-a[k]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += a[k];
+  out[(long)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 extern "C" {
 
 int hdmoe_axpby(void* out, const void* x, const void* y, float a, float b, long n, int dtype, hipStream_t stream) {
@@ -1001,6 +1017,11 @@ int hdmoe_heun_correct(float* out, const float* xh, const float* den, const floa
                        hipStream_t stream) {
   if (!out || !xh || !den || !xn || !den2 || !t || !idx) return HDMOE_EINVAL;
   L1D(heun_correct_kernel, n, out, xh, den, xn, den2, t, idx, n);
+  return hdmoe_launch_status();
+}
+int hdmoe_exp_rate(float* out, int blocks, int iters, hipStream_t stream) {
+  if (!out || blocks < 1 || iters < 1) return HDMOE_EINVAL;
+  hipLaunchKernelGGL(exp_rate_kernel, dim3(blocks), dim3(256), 0, stream, out, iters);
   return hdmoe_launch_status();
 }
 int hdmoe_sum_n(void* out, const void* const* srcs, const float* src_scale, int n, long nelem, int dtype, hipStream_t stream) {

@@ -130,6 +130,9 @@ int hdmoe_sched_pick(float* sigma, const double* t, const int* idx, int off, HS 
 int hdmoe_idx_advance(int* idx, HS stream);
 int hdmoe_heun_euler(float* xn, const float* xh, const float* den, const double* t, const int* idx, long n, HS stream);
 int hdmoe_heun_correct(float* out, const float* xh, const float* den, const float* xn, const float* den2, const double* t, const int* idx, long n, HS stream);
+/* Measurement aid: `blocks` x 256 threads, 8 x `iters` dependent v_exp_f32 per thread (out: blocks * 256 floats).  bench.py times it to state the
+ * transcendental issue rate the attention kernels (reference models/model_internals.py:374-404: one exp per score) are bounded by. */
+int hdmoe_exp_rate(float* out, int blocks, int iters, HS stream);
 int hdmoe_cast(void* out, const void* x, long n, int dt_in, int dt_out, HS stream);
 /* Separable even-length FIR resampling, channel-last (resample(x, f, mode) for f other than [1, 1]; reference models/model_internals.py:95-127):
  * up == 0: stride-2 depthwise correlation with outer(k, k) and padding `pad` (F.conv2d there); up == 1: its transpose (F.conv_transpose2d).
