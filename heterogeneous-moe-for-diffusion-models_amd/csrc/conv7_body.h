@@ -17,6 +17,8 @@
 //     and the epilogue stores in flight across the stage barriers.
 #pragma once
 #include <type_traits>
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -66,6 +68,8 @@ template <int KS, int CO, int TCO> struct C7Sched {
 
 struct C7Unit { int g, n, n2, ks; };
 
+template <typename F, int... I> DEVI void c7_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> DEVI void c7_static_for(F&& f) { c7_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 template <int N> DEVI void c7_wait_barrier() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory"); }
 
 template <int CO, int KMASK, bool W16>
@@ -210,10 +214,10 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
       const bool same_tile = last_chunk && !last_blk && CI == 1;
       const bool tile_next = (!last_chunk || (!last_blk && CI > 1) || (last_blk && has_next)) && !((a.dbg & 2) && last_chunk);
       const int tbase = T0 + tp * TILE;
-#pragma unroll
-      for (int s = 0; s < S::NS; ++s) {
-        const int kx = s / S::SPC, si = s % S::SPC;             // (compile-time after unrolling)
-        const int ky0 = S::ky0(si), nt = S::nt(si);
+      c7_static_for<S::NS>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int kx = s / S::SPC, si = s % S::SPC;
+        constexpr int ky0 = S::ky0(si), nt = S::nt(si);
         // ---- this stage's weights (and, at s == 0, this chunk's tile) have landed; the previous stage's buffers are free.
         //      vmcnt counts in issue order: what may stay in flight is whatever this wave issued AFTER the pieces it needs now
         if (s == 0) {
@@ -243,14 +247,14 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
         // ---- MFMAs of the stage: per 16-channel k-step, the nt + MB - 1 input rows it touches, then per kernel row its weight fragment(s)
         if (!(a.dbg & 1)) {
           const int wb = sp * WBUF;
-          const int row0 = MB * wave - P + ky0;                 // image row of fragment j = 0
+          const int row0 = MB * (tid >> 6) - P + ky0;           // image row of fragment j = 0 (per-lane arithmetic on purpose: the row bases then live in VGPRs, not in spilled SGPRs)
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2) {
             bf16x8 xf[7 + MB - 1];
 #pragma unroll
             for (int j = 0; j < nt + MB - 1; ++j) {
               const int row = row0 + j;
-              const int sb = ((unsigned)row < (unsigned)IMG) ? tbase + row * ROWB : ZROW;  // wave-uniform
+              const int sb = ((unsigned)row < (unsigned)IMG) ? tbase + row * ROWB : ZROW;
               xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((acol[kx + Q] ^ (k2 << 5)) + sb));
             }
 #pragma unroll
@@ -267,8 +271,19 @@ DEVI void conv7_body(const C7Args& a, const int bid, const int G) {
             }
           }
         }
+        // schedule of the stage's block: a few fragment reads ahead, then one read per MFMA until the reads run out (left alone the compiler
+        // puts every ds_read right in front of its first MFMA and a wave sits out the LDS latency once per tap)
+        if ((CO == 1 || W16) && !(a.dbg & 16)) {                // (two output blocks on 32 x 32 maps: 128 accumulator registers, the interleave spills)
+          constexpr int NRD = 2 * ((nt + MB - 1) + nt * CO), NMF = 2 * nt * MB * CO, LEAD = 4, R = NMF / NRD > 0 ? NMF / NRD : 1;
+          __builtin_amdgcn_sched_group_barrier(0x100, LEAD < NRD ? LEAD : NRD, 0);
+#pragma unroll
+          for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if ((q + 1) % R == 0 && LEAD + (q + 1) / R - 1 < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // (one read per R MFMAs: the reads end with the MFMAs)
+          }
+        }
         sp ^= 1;
-      }
+      });
       if (!same_tile) tp ^= 1;
     }
     const int cobase = blk * 32 * CO;

@@ -116,25 +116,31 @@ DEVI void wgrad7_body(const W6Args& a, const int bx, const int by, const int zsl
     int xb[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) xb[j] = sb + lbase + xoff[j] + pp * RPW * XROWB;
-#pragma unroll
-    for (int b = 0; b < RPW * 2; ++b) {                         // 16-pixel blocks of this wave's rows: (row b >> 1, half b & 1)
+    // 16-pixel blocks of this wave's rows: (row b >> 1, half b & 1).  Fragments through the asm reads (common.h: the compiler's own transposing
+    // reads would wait for the next unit's DMA first), requested one block ahead of their MFMAs (two register sets)
+    hd_s16x4 dlo[2], dhi[2], xlo[2][TPW], xhi[2][TPW];
+    auto request = [&](int b, int set) {
       const int rr = b >> 1, hh = b & 1;
-      // all fragments of the block requested at once through the asm reads (common.h: the compiler's own transposing reads would wait for
-      // the next unit's DMA first), one wait, then the MFMAs
-      hd_s16x4 dlo, dhi, xlo[TPW], xhi[TPW];
-      lds_tr2_issue(dlo, dhi, lds0 + dyb + rr * 2048 + hh * 1024, lds0 + dyb + rr * 2048 + hh * 1024 + 256);
+      lds_tr2_issue(dlo[set], dhi[set], lds0 + dyb + rr * 2048 + hh * 1024, lds0 + dyb + rr * 2048 + hh * 1024 + 256);
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const unsigned ad = lds0 + xb[j] + rr * XROWB + hh * 1024;
-        lds_tr2_issue(xlo[j], xhi[j], ad, ad + 256);
+        lds_tr2_issue(xlo[set][j], xhi[set][j], ad, ad + 256);
       }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int b = 0; b < RPW * 2; ++b) {
       lds_tr_wait();
-      const bf16x8 fdy = lds_tr2_take(dlo, dhi);
+      const bf16x8 fdy = lds_tr2_take(dlo[b & 1], dhi[b & 1]);
+      bf16x8 fx[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) fx[j] = lds_tr2_take(xlo[b & 1][j], xhi[b & 1][j]);
+      if (b + 1 < RPW * 2) request(b + 1, (b + 1) & 1);
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        const bf16x8 fx = lds_tr2_take(xlo[j], xhi[j]);
         if (NTAPS % NG == 0 || j + 1 < TPW || tvalid[j])       // (only a group's last tap can be missing)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy, fx, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdy, fx[j], acc[j], 0, 0, 0);
       }
     }
   }
