@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from hdmoe_hip import graph as hgraph
 from hdmoe_hip import ops
 
 
@@ -73,7 +74,7 @@ class EDM_Sampler:
                     self.denoise(self._sx, self._ssig, self._stext, transition_mean, softness, self._sunc)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with hgraph.no_gc(), torch.cuda.graph(self._graph):
                 self._sout = self.denoise(self._sx, self._ssig, self._stext, transition_mean, softness, self._sunc)
             self._gkey = key
         # every replay input is refreshed: a later sample() with another prompt of the same shape must not see the captured one
@@ -124,10 +125,11 @@ class EDM_Sampler:
             torch.cuda.current_stream().wait_stream(side)
             st["g_heun"], st["g_last"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             st["idx"].zero_()
-            with torch.cuda.graph(st["g_heun"]):
-                stage(False)
-            with torch.cuda.graph(st["g_last"], pool=st["g_heun"].pool()):
-                stage(True)
+            with hgraph.no_gc():
+                with torch.cuda.graph(st["g_heun"]):
+                    stage(False)
+                with torch.cuda.graph(st["g_last"], pool=st["g_heun"].pool()):
+                    stage(True)
         self._stage, self._skey = st, key
         return st
 

@@ -26,6 +26,26 @@ def _capture_mode() -> str:
     return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def no_gc():
+    """Python's cyclic collector must not run inside a stream capture: collecting a dead graph, stream or event of an EARLIER capture (a
+    test's StagedStep, a sampler's stage graphs -- all cycles) calls hipGraphDestroy / hipEventDestroy from the capturing thread, the
+    runtime refuses that inside a global-mode capture and the destructor's exception ends the process ("Fatal Python error: Aborted ...
+    Garbage-collecting" in the middle of a capture, once in a few hundred runs).  Collect before, keep the collector off until the end."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class GraphedStep:
     def __init__(self, step_fn, device, warmup: int = 3):
         """``step_fn()`` must be re-runnable with static inputs and write its results into persistent tensors."""
@@ -39,7 +59,7 @@ class GraphedStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
+        with no_gc(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             ops.advance_seed(self.device)
             self.out = step_fn()
             bank.join_forked_streams()                  # every forked side stream is back on the capture stream
@@ -76,16 +96,17 @@ class Stager:
     ``graph.current()``: ``cut(stage, **tensors_by_producer_stage)`` at a boundary, ``backward(loss)`` instead of loss.backward()."""
 
     KIND = {"pre": "main", "ur": "r", "unet": "u", "vit": "v", "post": "main", "ucomb_bwd": "u", "ur_bwd": "r", "unet_bwd": "u", "vit_bwd": "v",
-            "pre_bwd": "main", "unet_bwd2": "u", "unet_bwd1": "u", "unet_bwd0": "u", "vcomb_bwd": "v", "vr_bwd": "r"}
+            "pre_bwd": "main", "unet_bwd2": "u", "unet_bwd1": "u", "unet_bwd0": "u", "vcomb_bwd": "v", "vr_bwd": "main"}
     # SPLIT_VROUTER (round 4): with the U-Net bank's backward down to ~6 ms the ViT section became the LAST one to finish (stage_ms: vit_bwd
     # 6.2 -> 12.8 ms, unet_bwd0 ends at 12.4): its stream runs the ViT bank's backward (~170 small launches) and then the ViT router's trunk
     # backward (the heavy part) one after the other.  The router's backward needs only the gradient of the routing weights, which the
     # combine backward -- the section's first kernel -- produces: same cut as for the U-Net router (`vcomb_bwd` on the ViT stream, then
-    # `vr_bwd` beside `vit_bwd`).  The forward stays one graph.  HDMOE_VR_STREAM: the stream of `vr_bwd`.  Same box, ms/step: no split 13.39;
-    # "r" (behind the U-Net router's backward; default) 13.13; "main" (idle between `post` and `pre_bwd`, but prioritised like the U-Net
-    # stream: it takes CUs from the critical path) 13.32; "r2" (a fifth stream of our own) 17.9 -- see the note on hardware queues below.
+    # `vr_bwd` beside `vit_bwd`).  The forward stays one graph.  HDMOE_VR_STREAM: the stream of `vr_bwd`.  Same box, ms/step, with the stream
+    # priorities of the time: no split 13.39; "r" (behind the U-Net router's backward) 13.13; "main" (idle between `post` and `pre_bwd`) 13.32;
+    # "r2" (a fifth stream of our own) 17.9 -- see the note on hardware queues below.  Without priorities (the default now, see StagedStep):
+    # "main" 13.02, "r" 13.62.
     SPLIT_VROUTER = __import__("os").environ.get("HDMOE_SPLIT_VROUTER", "1") != "0"
-    KIND["vr_bwd"] = __import__("os").environ.get("HDMOE_VR_STREAM", "r")
+    KIND["vr_bwd"] = __import__("os").environ.get("HDMOE_VR_STREAM", "main")
     # SPLIT_UNET_BWD (round 4): the U-Net bank's backward as up to FOUR sections on its stream -- decoder at full resolution (+ output conv),
     # decoder below, encoder below, encoder at full resolution (+ embeddings) -- cut with detached leaves inside the forward graph
     # (models/model_components.py unet_expert_bank_forward).  Each section finishes its own weight gradients (bank.finish_stage), so its
@@ -237,9 +258,15 @@ class StagedStep:
         # stages serialise: measured under the one-rank RCCL group 4 queues 17.2, 8 queues 17.4, 6 queues 20.4 ms/step; without a group
         # and without priorities 4 queues 18.0, 8 queues 17.6; a ONE-graph replay with an internal fork (the sampler) is 20 % slower
         # with 8 queues than with 4.  The default (4) is the best setting for every configuration the code itself selects.
-        import torch.distributed as dist
-        pmode = __import__("os").environ.get("HDMOE_STREAM_PRIO", "auto")
-        use_prio = pmode == "1" or (pmode == "auto" and not (dist.is_available() and dist.is_initialized()))
+        # ROUND 4: stream priorities are OFF by default.  With prioritised streams, replays launched back to back (the host a replay ahead of the
+        # device -- what a training loop and bench.py do) showed a transient: in 2-6 % of the replays the router logits of the LOW-priority branch
+        # came out with a bf16-sized error (5e-3 .. 3e-2 against 8e-5), gone in the next replay (tools/replay_race.py: 51 outliers in 900 bursts of
+        # three replays; 0 in 1800 bursts without priorities, 0 with a synchronize between the replays; it survives dropping every backward section
+        # from the replay, so it sits between `pre` / the forward branches of neighbouring replays).  The event dependencies are the same either
+        # way; which wait the prioritised queues do not honour was not isolated.  Without priorities the schedule needs `vr_bwd` on the `main`
+        # stream to keep the step time (12.98 prioritised, 13.02 equal priorities + vr_bwd on main, 13.62 equal priorities + vr_bwd behind ur_bwd).
+        pmode = os.environ.get("HDMOE_STREAM_PRIO", "0")
+        use_prio = pmode == "1"
         prio = {"main": -1, "u": -1, "v": 0, "r": 0} if use_prio else {"main": 0, "u": 0, "v": 0, "r": 0}
         names = ("main", "u", "v", "r") + (("r2",) if Stager.KIND["vr_bwd"] == "r2" else ())
         prio["r2"] = 0
@@ -253,7 +280,8 @@ class StagedStep:
         for s in self.streams.values():
             cur.wait_stream(s)
         torch.cuda.synchronize(self.device)
-        st = self._run(step_fn, capture=True)
+        with no_gc():
+            st = self._run(step_fn, capture=True)
         core = [n for n in st.order if n not in ("unet_bwd2", "unet_bwd1", "unet_bwd0", "vcomb_bwd", "vr_bwd")]
         self.split_vr = "vr_bwd" in st.order                      # the ViT router's backward as its own section (Stager.SPLIT_VROUTER)
         if core not in (self.ORDER, self.ORDER_R):

@@ -213,8 +213,29 @@ def test_staged_train_mode_replay_matches_the_reference(golden_wide, split_route
                 w0, w1 = state0[n], dict(model.named_parameters())[n].detach().cpu()
                 fac = (1e-4 + rms(w0)) / (1e-4 + rms(w1))
                 gfix["param_grads"][n] = gref * fac.view(-1, *([1] * (gref.ndim - 1)))
+        # back-to-back replays (the host ahead of the device, as in a training loop): the logits of every burst's last replay.  Under prioritised
+        # streams 2-6 % of them were off by 5e-3 .. 3e-2 (hdmoe_hip/graph.py StagedStep; tools/replay_race.py) -- none may be.
+        if g["cfg_id"] == 1:
+            worst = 0.0
+            for _ in range(40):
+                for _ in range(3):
+                    staged()
+                torch.cuda.synchronize()
+                for k_ in ("vit_raw", "Unet_raw"):
+                    fin = torch.isfinite(g["out"][k_])
+                    worst = max(worst, float((keep["out"][k_].float().cpu() - g["out"][k_])[fin].abs().max()))
+            assert worst < 5e-4, f"router logits moved by {worst:.2e} in a burst of back-to-back replays"
         tag = f"staged_cfg{g['cfg_id']}_{'ten' if split_router else 'seven'}_graphs"
-        _measured[tag] = _check(gfix, kw, keep["out"], x.grad, pg, 3e-2, 1e-1, 6e-2, tag)
+        try:
+            _measured[tag] = _check(gfix, kw, keep["out"], x.grad, pg, 3e-2, 1e-1, 6e-2, tag)
+        except AssertionError as first:
+            # diagnosis aid: is the miss static (every further replay shows it) or does it move?  The logit errors of six more replays ride along.
+            trace = []
+            for _ in range(6):
+                staged()
+                torch.cuda.synchronize()
+                trace.append([float((keep["out"][k_].float().cpu() - g["out"][k_])[torch.isfinite(g["out"][k_])].abs().max()) for k_ in ("vit_raw", "Unet_raw")])
+            raise AssertionError(f"{first}\nlogit errors [vit, unet] of six further replays: {trace}") from first
         _measured[tag]["loss_rel"] = abs(float(l_g) - float(g["loss"]["loss"])) / abs(float(g["loss"]["loss"]))
     finally:
         hdmoe_hip.set_compute_dtype(torch.float32)
