@@ -437,12 +437,14 @@ def main():
 
     step = eager_step
     graphed = None
+    n_staged = 1
     if not args.no_graph:
         # the step is ~2.4k launches: replay it as one hipGraph (fwd + loss + bwd + weight-gradient finish); the gradient
         # all-reduce stays outside the graph and runs right after the replay
         buckets.enabled = False                             # no collectives from autograd hooks while capturing
         try:
             graphed = GraphedStep(fwd_bwd, device) if args.single_graph else StagedStep(fwd_bwd, device)
+            n_staged = len(getattr(graphed, "graphs", {})) or 1
         except Exception as exc:                            # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
             graphed = None
@@ -587,7 +589,7 @@ def main():
             buckets.enabled = True
     roof, table = (None, {})
     cpu = None
-    launch_desc = "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({len(getattr(graphed, 'graphs', {})) or 1} staged graphs, expert branches on their own streams)")
+    launch_desc = "eager" if args.no_graph else ("hipGraph replay (one graph)" if args.single_graph else f"hipGraph replay ({n_staged} staged graphs, expert branches on their own streams)")
     roof_unfused = None
     attention_rep = None
     sampler_rec = None
